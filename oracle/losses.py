@@ -1,0 +1,89 @@
+"""oracle/losses.py -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+torch-CPU fp32 restatement of the loss assembly on the hot path:
+  detection_set_loss   training/train_bdd100k_ddp.py:117-186
+  segmentation_loss    training/train_bdd100k_ddp.py:58,188-194
+  gating_losses        training/train_gating_network.py:21-74
+  train_step           the step glue of train_bdd100k_ddp.py:89-100 / train_gating_network.py:92-105
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from .matcher import HungarianMatcher, box_xyxy_to_cxcywh
+
+
+def detection_set_loss(model_out: Dict[str, torch.Tensor], gt_boxes: torch.Tensor, gt_labels: torch.Tensor,
+                       num_classes: int, matcher: HungarianMatcher, bbox_loss_weight: float = 2.0):
+    """gt_boxes [B,Nmax,4] xyxy pixels padded with -1, gt_labels [B,Nmax] padded with -1.
+    Returns (total, class_loss, bbox_loss, indices)."""
+    logits, boxes = model_out["class_logits"], model_out["bbox_deltas"]
+    B, C, H, W = logits.shape
+    Q = H * W
+    logits = logits.permute(0, 2, 3, 1).reshape(B, Q, C)
+    boxes = boxes.permute(0, 2, 3, 1).reshape(B, Q, 4)
+    targets = []
+    for b in range(B):
+        keep = gt_labels[b] != -1
+        bx = gt_boxes[b][keep]
+        targets.append({"boxes": box_xyxy_to_cxcywh(bx) if bx.numel() > 0 else bx, "labels": gt_labels[b][keep]})
+    indices = matcher({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    tgt_cls = torch.full((B * Q,), num_classes, dtype=torch.int64)
+    tgt_box = torch.zeros((B * Q, 4), dtype=torch.float32)
+    for b, (pi, ti) in enumerate(indices):
+        tgt_cls[b * Q + pi] = targets[b]["labels"][ti]
+        tgt_box[b * Q + pi] = targets[b]["boxes"][ti]
+    cls_loss = F.cross_entropy(logits.reshape(B * Q, C), tgt_cls, ignore_index=num_classes)
+    matched = tgt_cls != num_classes
+    if matched.any():
+        box_loss = F.smooth_l1_loss(boxes.reshape(B * Q, 4)[matched], tgt_box[matched], reduction="mean")
+    else:
+        box_loss = torch.tensor(0.0)
+    return cls_loss + bbox_loss_weight * box_loss, cls_loss, box_loss, indices
+
+
+def segmentation_loss(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    return F.cross_entropy(logits, mask, ignore_index=255)
+
+
+def gating_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor, target_spd: torch.Tensor,
+                  config: Dict) -> Dict[str, torch.Tensor]:
+    wp = pred["waypoints"]
+    ade = F.l1_loss(wp, target_wp)
+    fde = F.l1_loss(wp[:, -1, :], target_wp[:, -1, :])
+    ps = pred.get("speed_seq", pred.get("speed"))
+    if ps is not None and ps.dim() == 2 and target_spd.dim() == 2 and ps.size(1) == target_spd.size(1):
+        spd = F.l1_loss(ps, target_spd)
+    else:
+        pl = pred.get("speed")
+        if pl is not None and pl.dim() == 2 and pl.size(1) == 1:
+            spd = F.l1_loss(pl, target_spd[:, -1:].contiguous())
+        else:
+            spd = torch.zeros(())
+    d = wp[:, 1:, :] - wp[:, :-1, :]
+    smooth = F.l1_loss(d[:, 1:, :], d[:, :-1, :])
+    w = pred["expert_weights"]
+    if config.get("use_load_balancing", True):
+        usage = w.mean(dim=0)
+        lb = F.mse_loss(usage, torch.ones_like(usage) / usage.size(0))
+    else:
+        lb = torch.tensor(0.0)
+    if config.get("use_entropy_loss", True):
+        ent = (w * torch.log(w + 1e-8)).sum(dim=1).mean()  # = -entropy
+    else:
+        ent = torch.tensor(0.0)
+    total = (config.get("ade_weight", 1.0) * ade + config.get("fde_weight", 2.0) * fde
+             + config.get("speed_weight", 0.2) * spd + config.get("smoothness_weight", 0.1) * smooth
+             + config.get("load_balancing_weight", 0.01) * lb + config.get("entropy_weight", 0.001) * ent)
+    return {"total_loss": total, "ade": ade, "fde": fde, "speed": spd, "smoothness": smooth,
+            "load_balancing": lb, "entropy": ent}
+
+
+def clip_and_step(params: List[torch.Tensor], optimizer: torch.optim.Optimizer, max_norm: float = 1.0):
+    """clip_grad_norm_(max_norm) + optimizer.step(); returns the pre-clip total norm."""
+    norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+    optimizer.step()
+    return norm
