@@ -1,0 +1,218 @@
+/* automoe_hip.h -- C ABI of libautomoe_hip.so: the gfx950 (MI355X) kernels behind the AutoMoE
+ * data-parallel train-step hot path.
+ *
+ * The reference (immanuel-peter/self-driving-model) is pure Python; it has no FFI of its own.
+ * Its "operator API" for this path is torch.nn / torchvision / scipy calls, so every entry point
+ * below names the reference call site (file:line under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C symbols, raw device pointers + sizes + a hipStream_t (passed as void*); no torch types;
+ *   - every call returns int: AM_OK (0) or a negative AM_ERR_* code; nothing throws across the ABI;
+ *   - the caller owns every buffer; the library allocates nothing and keeps no global mutable
+ *     state, so calls on different streams are independent;
+ *   - all launches are asynchronous on `stream`; no call synchronises the device;
+ *   - activations are NHWC ("pixel-major") with element type `dtype` (AM_F32 or AM_F16);
+ *     accumulation is always fp32 (fp64 for BatchNorm statistics).
+ */
+#ifndef AUTOMOE_HIP_H
+#define AUTOMOE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AM_OK 0
+#define AM_ERR_ARG (-1)         /* bad argument (null pointer, bad size, unsupported shape) */
+#define AM_ERR_LAUNCH (-2)      /* the HIP runtime refused the launch */
+#define AM_ERR_UNSUPPORTED (-3) /* shape/dtype combination not built */
+
+#define AM_F32 0
+#define AM_F16 1
+
+#define AM_MAX_TAPS 16
+#define AM_STATS_REPLICAS 16
+
+typedef void* am_stream_t; /* hipStream_t */
+
+int am_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM ("gather-GEMM").
+ * Replaces torch.nn.Conv2d forward / input-gradient at: ResNet-18 trunk convs
+ * (models/experts/bdd_detection_expert.py:9-10 via torchvision), expert heads
+ * (bdd_detection_expert.py:12-16, bdd_segmentation_expert.py:13-17, bdd_drivable_expert.py:13-17),
+ * EasyBackbone convs (models/policy/trajectory_head.py:9-22), and their autograd backward
+ * (training/train_bdd100k_ddp.py:97, training/train_gating_network.py:101).
+ *
+ * One geometry struct describes forward, stride-1 dgrad and each parity class of a strided
+ * dgrad: output row m -> (image n, my, mx) on an MH x MW sub-grid;
+ *   output pixel  = (my*oys + oy0, mx*oxs + ox0) of an OH x OW image, pixel stride ldo elements;
+ *   tap t gathers `krun` contiguous elements starting at input pixel (my*iys + dy[t], mx*ixs + dx[t]),
+ *   channel x_coff, of an IH x IW image with pixel stride ldi elements; chunks (16 B) whose pixel
+ *   falls outside the image read as zero (that is the conv zero padding).
+ * GEMM view: M = B*MH*MW rows, K = ntaps*krun, N output channels;
+ *   y[m, n] = act( sum_k gather(m, k) * w[n, k] + bias[n] ).
+ * Packed weights `w`: row-major [am_conv_npad(N)][ntaps*krun] of `dtype`, zero padded rows.
+ * krun*sizeof(dtype) must be a multiple of 64.  pix_shift: log2(elements per input pixel) when a
+ * run spans several pixels (first-layer trick: 8 pixels x 8 channels), 31 when it covers one.
+ * `stats` (optional, may be NULL): [AM_STATS_REPLICAS][2][N] fp64, zeroed by the caller;
+ * receives per-channel sum and sum of squares of the pre-bias accumulator (BatchNorm batch
+ * statistics, torch.nn.BatchNorm2d in train mode) -- bias-free so the variance is shift-free.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct am_conv_geom {
+  int32_t B, MH, MW;
+  int32_t IH, IW, ldi, x_coff;
+  int32_t OH, OW, ldo, y_coff;
+  int32_t oys, oy0, oxs, ox0;
+  int32_t iys, ixs;
+  int32_t ntaps, krun, pix_shift;
+  int32_t N;
+  int16_t dy[AM_MAX_TAPS];
+  int16_t dx[AM_MAX_TAPS];
+} am_conv_geom;
+
+int am_conv_npad(int N);
+int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w, const float* bias,
+                 int relu, void* y, double* stats, am_stream_t stream);
+
+/* Weight gradient of the same gather-GEMM (torch conv2d backward w.r.t. weight):
+ *   dw[n, t*krun + r] += scale * sum_m dy[m, n] * gather(m, t, r),  fp32, atomically accumulated,
+ * dw row-major [>=N rows][ntaps*krun] (caller zeroes it, e.g. zero_grad).  `dy` is read at the
+ * geometry's OUTPUT pixels (pixel stride ldo, channel y_coff).  `scale` undoes loss scaling. */
+int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale,
+                  float* dw, am_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d around the conv (torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1: ResNet-18 via
+ * bdd_*_expert.py:9-11; models/policy/trajectory_head.py:10-22).  P = pixels (B*H*W), NHWC rows with
+ * leading dimension ld* (elements).
+ *   am_bn_finalize   training: batch mean/var from the conv's fp64 sums (+conv bias), updates the
+ *                    running stats (unbiased var), emits scale = gamma*rstd, shift = beta - mean*scale
+ *                    and saves mean/rstd for backward.  eval: scale/shift from the running stats.
+ *   am_bn_apply      y = act(x*scale + shift (+ residual))      (BasicBlock add + ReLU fused)
+ *   am_bn_bwd_*      dz = dy * (yout > 0); sums = [sum dz, sum dz*xhat] (fp64 replicas);
+ *                    finalize: dgamma += gscale*sum dz*xhat, dbeta += gscale*sum dz, coef[3][C];
+ *                    apply: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)), dz_out = dz.
+ *   am_bias_relu_bwd heads (conv + bias + ReLU, no BN): dz = dy*(yout>0), dbias += gscale*colsum(dz).
+ * ------------------------------------------------------------------------------------------ */
+int am_bn_finalize(const double* stats, int nrep, double count, const float* conv_bias, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                   int training, float* scale, float* shift, float* save_mean, float* save_rstd, int C,
+                   am_stream_t stream);
+int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
+                int relu, void* y, int ldy, long long P, int C, am_stream_t stream);
+int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                     const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
+                     am_stream_t stream);
+int am_bn_bwd_finalize(const double* sums, int nrep, double count, const float* gamma, const float* rstd,
+                       float gscale, float* dgamma, float* dbeta, float* coef, int C, am_stream_t stream);
+int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                    const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
+                    void* dz_out, int lddz, long long P, int C, am_stream_t stream);
+int am_bias_relu_bwd(int dtype, const void* dy, int lddy, const void* yout, int ldyo, int relu, void* dz_out,
+                     int lddz, float* dbias, float gscale, long long P, int C, int Cvalid, am_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spatial, HBM-bound kernels.
+ *   am_nchw_to_nhwc / am_nhwc_to_nchw   boundary layout change: the reference API is NCHW fp32
+ *       ([B,3,H,W] images, [B,C,h,w] head outputs); inside, activations are NHWC `dtype` with the
+ *       channel count padded to `ld`.
+ *   am_maxpool3x3s2_*    nn.MaxPool2d(3,2,1) of the ResNet stem (first max in scan order wins).
+ *   am_gap_nhwc_*        nn.AdaptiveAvgPool2d(1) on NHWC activations (trajectory_head.py:25).
+ *   am_gap_plane_*       the same over NCHW fp32 planes (expert_extractors.py:28,62,89).
+ *   am_bilinear_up_*     F.interpolate(mode='bilinear', align_corners=False)
+ *                        (bdd_segmentation_expert.py:22, bdd_drivable_expert.py:22): low-res NHWC
+ *                        `dtype` -> full-res NCHW fp32 and its adjoint (x mul x *dev_scale).
+ *   am_ce2d_*            nn.CrossEntropyLoss(ignore_index) over [B,C,H,W] logits and int64 targets
+ *                        (train_bdd100k_ddp.py:58,193); acc2 = {sum of losses, valid count} fp64 on
+ *                        the device; backward reads the count and grad_out from device memory.
+ * ------------------------------------------------------------------------------------------ */
+int am_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ld, float mul,
+                    am_stream_t stream);
+int am_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int ld, float mul,
+                    am_stream_t stream);
+int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int B, int IH, int IW, int C,
+                        am_stream_t stream);
+int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
+                        am_stream_t stream);
+int am_gap_nhwc_fwd(int dtype, const void* x, int ld, float* out, int B, int P, int C, am_stream_t stream);
+int am_gap_nhwc_bwd(int dtype, const float* dout, void* dx, int ld, int B, int P, int C, float mul,
+                    am_stream_t stream);
+int am_gap_plane_fwd(const float* x, float* out, long long planes, long long HW, am_stream_t stream);
+int am_gap_plane_bwd(const float* dout, float* dx, long long planes, long long HW, am_stream_t stream);
+int am_bilinear_up_fwd(int dtype, const void* low, int ld, float* out, int B, int C, int h, int w, int H, int W,
+                       am_stream_t stream);
+int am_bilinear_up_bwd(int dtype, const float* dout, void* dlow, int ld, int B, int C, int h, int w, int H, int W,
+                       float mul, const float* dev_scale, am_stream_t stream);
+int am_ce2d_fwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
+                double* acc2, am_stream_t stream);
+int am_ce2d_bwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
+                const double* acc2, const float* grad_out, float* dlogits, am_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MoE tail (fp32): nn.Linear / ReLU / Dropout / LayerNorm of expert_extractors.py:30-34,
+ * context_features.py:143-149, gating_network.py:13-20,38-44,93-100,168, trajectory_head.py:26,44-53,
+ * and the gate (gating_network.py:149-166): weights = softmax(logits/T) or sigmoid-normalise, with
+ * optional top-k masking; combined = sum_e w[:,e] * P_e.
+ * Linear: W is [N][K] row-major (nn.Linear.weight); `yact` (optional) is the post-ReLU output whose
+ * sign masks dy in the backward kernels; bwd_weight ACCUMULATES into dW / dbias.
+ * ------------------------------------------------------------------------------------------ */
+#define AM_MAX_EXPERTS 8
+int am_linear_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int M, int N,
+                  int K, int relu, am_stream_t stream);
+int am_linear_bwd_input(const float* dy, int lddy, const float* yact, int ldya, const float* W, float* dx, int lddx,
+                        int M, int N, int K, int accumulate, am_stream_t stream);
+int am_linear_bwd_weight(const float* dy, int lddy, const float* yact, int ldya, const float* x, int ldx, float* dW,
+                         float* dbias, int M, int N, int K, am_stream_t stream);
+int am_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                     float* mean, float* rstd, int M, int D, am_stream_t stream);
+int am_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                     const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int M, int D,
+                     am_stream_t stream);
+int am_gate_combine_fwd(const float* logits, const float* const* processed, int E, int ldp, float temperature,
+                        int use_softmax, int top_k, float* weights, float* combined, int B, int D,
+                        am_stream_t stream);
+int am_gate_combine_bwd(const float* logits, const float* const* processed, int E, int ldp, float temperature,
+                        int use_softmax, int top_k, const float* dcombined, const float* dweights_ext,
+                        float* dlogits, float* const* dprocessed, int B, int D, am_stream_t stream);
+int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, unsigned long long seed,
+                   am_stream_t stream);
+int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, am_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hungarian matcher (training/hungarian_matcher.py:20-85).
+ *   am_match_cost    per image b and query q: C = w_bbox*L1(cxcywh) + w_class*(-softmax prob at the
+ *                    GT label) + w_giou*(-GIoU), summed in that order in fp32; written TRANSPOSED,
+ *                    cost[b][j][q] (j < n_tgt[b], leading dims Nmax and Q), so the solver reads rows.
+ *   am_lsap_batched  scipy.optimize.linear_sum_assignment per image, fp32 costs promoted to fp64:
+ *                    cost(i,j) at cost[b*batch_stride + i*row_stride + j*col_stride], i < nr,
+ *                    j < nc_per[b].  Outputs int64 pairs sorted by row (row_idx/col_idx [B][kmax]),
+ *                    count[b] = min(nr, nc), status[b] = 0 ok, -1 infeasible, -2 NaN/-inf entry
+ *                    (scipy raises ValueError for both).  Bit-exact with scipy, ties included.
+ * ------------------------------------------------------------------------------------------ */
+int am_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels, const float* tgt_boxes,
+                  const int32_t* n_tgt, int B, int Q, int C, int Nmax, float w_class, float w_bbox, float w_giou,
+                  float* cost, am_stream_t stream);
+int am_lsap_batched(const float* cost, int B, int nr, const int32_t* nc_per, int nc_max, long long batch_stride,
+                    long long row_stride, long long col_stride, int64_t* row_idx, int64_t* col_idx, int kmax,
+                    int32_t* count, int32_t* status, am_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step glue on flat fp32 buffers (train_bdd100k_ddp.py:98-99, train_gating_network.py:103-105):
+ * global grad norm kept on the device, clip_grad_norm_(max_norm) folded into the AdamW update
+ * (torch.optim.AdamW arithmetic), non-finite norm => step skipped and counted.
+ * ------------------------------------------------------------------------------------------ */
+int am_sumsq_accumulate(const float* x, long long n, double* acc, am_stream_t stream);
+int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
+                  am_stream_t stream);
+int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOMOE_HIP_H */

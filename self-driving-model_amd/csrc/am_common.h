@@ -1,0 +1,55 @@
+// Shared definitions for the gfx950 kernels behind include/automoe_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/automoe_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define AM_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e_ = hipGetLastError();                      \
+    if (e_ != hipSuccess) return AM_ERR_LAUNCH;             \
+  } while (0)
+
+template <typename T> struct am_dtype_of;
+template <> struct am_dtype_of<float> { static constexpr int value = AM_F32; };
+template <> struct am_dtype_of<half_t> { static constexpr int value = AM_F16; };
+
+__device__ __forceinline__ float am_to_f32(float v) { return v; }
+__device__ __forceinline__ float am_to_f32(half_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T am_from_f32(float v);
+template <> __device__ __forceinline__ float am_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ half_t am_from_f32<half_t>(float v) { return (half_t)v; }
+
+// 64-lane wave reductions (CDNA wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware block remap (8 XCDs, round-robin dispatch): gives each XCD a contiguous range of
+// logical block ids so neighbouring tiles share an L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+static inline int am_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,327 @@
+// BatchNorm2d (train and eval) around the conv gather-GEMM, NHWC, HBM-bound elementwise kernels.
+// Forward: conv epilogue -> fp64 per-channel sums (conv_gemm.hip) -> am_bn_finalize -> am_bn_apply
+// (normalise + optional residual add + ReLU in one pass, 16 B per lane).
+// Backward: am_bn_bwd_reduce (sum dz, sum dz*xhat; ReLU mask from the saved output) ->
+// am_bn_bwd_finalize -> am_bn_bwd_apply (dx, and dz for the residual branch).
+#include "am_common.h"
+
+namespace {
+
+__global__ void bn_finalize_k(const double* __restrict__ stats, int nrep, double count, const float* __restrict__ conv_bias,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                              float* save_mean, float* save_rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, rstd;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < nrep; ++r) {
+      s += stats[(size_t)r * 2 * C + c];
+      q += stats[(size_t)r * 2 * C + C + c];
+    }
+    const double m0 = s / count;
+    double var = q / count - m0 * m0;
+    if (var < 0.0) var = 0.0;
+    const double m = m0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  } else {
+    mean = running_mean[c];
+    rstd = 1.0f / sqrtf(running_var[c] + eps);
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rstd;
+  shift[c] = b - mean * g * rstd;
+  if (save_mean) save_mean[c] = mean;
+  if (save_rstd) save_rstd[c] = rstd;
+}
+
+template <typename T>
+struct Vec16 {
+  static constexpr int N = 16 / (int)sizeof(T);
+  T v[N];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                  int relu, T* __restrict__ y, int ldy, long long P, int C) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int cpr = C / E;  // chunks per pixel row
+  const long long total = P * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * E;
+    Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
+    Vec16<T> rv;
+    if (res) rv = *reinterpret_cast<const Vec16<T>*>(res + pix * ldr + c0);
+    Vec16<T> out;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float v = am_to_f32(xv.v[e]) * scale[c0 + e] + shift[c0 + e];
+      if (res) v += am_to_f32(rv.v[e]);
+      if (relu) v = fmaxf(v, 0.f);
+      out.v[e] = am_from_f32<T>(v);
+    }
+    *reinterpret_cast<Vec16<T>*>(y + pix * ldy + c0) = out;
+  }
+}
+
+// One workgroup strides over pixel rows; thread t owns channel chunk (t % cpr) for rows t / cpr + k*rpb.
+// Partial sums stay in registers; block-level LDS reduce; fp64 atomics into replicas.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* __restrict__ dy, int lddy, const T* __restrict__ yout, int ldyo,
+                                                       const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int relu, double* __restrict__ sums,
+                                                       long long P, int C) {
+  constexpr int E = 16 / (int)sizeof(T);
+  extern __shared__ float red[];  // [256][2*E]
+  const int cpr = C / E;
+  const int tid = threadIdx.x;
+  // threads are laid out [rows_per_pass][cpr]; threads beyond rows_per_pass*cpr idle
+  const int rpp = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = tid % cpr, rloc = tid / cpr;
+  float s[E], q[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = q[e] = 0.f;
+  if (cpr <= 256 && rloc < rpp) {
+    const int c0 = chunk * E;
+    float mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; }
+    for (long long pix = (long long)blockIdx.x * rpp + rloc; pix < P; pix += (long long)gridDim.x * rpp) {
+      Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(dy + pix * lddy + c0);
+      Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
+      Vec16<T> yo;
+      if (relu) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float dz = am_to_f32(g.v[e]);
+        if (relu && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+        s[e] += dz;
+        q[e] += dz * (am_to_f32(xv.v[e]) - mu[e]) * rs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) { red[tid * 2 * E + e] = s[e]; red[tid * 2 * E + E + e] = q[e]; }
+  __syncthreads();
+  // thread (chunk, e) pairs: C*2 outputs; reduce over rloc
+  for (int o = tid; o < cpr * E * 2; o += 256) {
+    const int which = o / (cpr * E), ce = o % (cpr * E);
+    const int ch = ce / E, e = ce % E;
+    double a = 0.0;
+    for (int r = 0; r < rpp; ++r) a += (double)red[(r * cpr + ch) * 2 * E + which * E + e];
+    atomicAdd(sums + (size_t)(blockIdx.x % AM_STATS_REPLICAS) * 2 * C + (size_t)which * C + ce, a);
+  }
+}
+
+__global__ void bn_bwd_finalize_k(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
+                                  const float* __restrict__ rstd, float gscale, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, float* __restrict__ coef, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    s += sums[(size_t)r * 2 * C + c];
+    q += sums[(size_t)r * 2 * C + C + c];
+  }
+  if (dgamma) dgamma[c] += (float)(q * gscale);
+  if (dbeta) dbeta[c] += (float)(s * gscale);
+  const float g = gamma ? gamma[c] : 1.f;
+  coef[c] = g * rstd[c];                 // c1
+  coef[C + c] = (float)(s / count);      // mean(dz)
+  coef[2 * C + c] = (float)(q / count);  // mean(dz*xhat)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* __restrict__ dy, int lddy, const T* __restrict__ yout, int ldyo,
+                                                      const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ coef, int relu,
+                                                      T* __restrict__ dx, int lddx, T* __restrict__ dz_out, int lddz,
+                                                      long long P, int C) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int cpr = C / E;
+  const long long total = P * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * E;
+    Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(dy + pix * lddy + c0);
+    Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
+    Vec16<T> yo;
+    if (relu) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
+    Vec16<T> o, z;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = c0 + e;
+      float dz = am_to_f32(g.v[e]);
+      if (relu && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+      const float xhat = (am_to_f32(xv.v[e]) - mean[c]) * rstd[c];
+      o.v[e] = am_from_f32<T>(coef[c] * (dz - coef[C + c] - xhat * coef[2 * C + c]));
+      z.v[e] = am_from_f32<T>(dz);
+    }
+    *reinterpret_cast<Vec16<T>*>(dx + pix * lddx + c0) = o;
+    if (dz_out) *reinterpret_cast<Vec16<T>*>(dz_out + pix * lddz + c0) = z;
+  }
+}
+
+// dz = dy * (y > 0) (optional), written to dz_out (optional), column sums -> dbias (fp32, += scale*sum)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_relu_bwd_k(const T* __restrict__ dy, int lddy, const T* __restrict__ yout, int ldyo,
+                                                       int relu, T* __restrict__ dz_out, int lddz, float* __restrict__ dbias,
+                                                       float gscale, long long P, int C, int Cvalid) {
+  constexpr int E = 16 / (int)sizeof(T);
+  extern __shared__ float red[];  // [256][E]
+  const int cpr = C / E;
+  const int tid = threadIdx.x;
+  const int rpp = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = tid % cpr, rloc = tid / cpr;
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (cpr <= 256 && rloc < rpp) {
+    const int c0 = chunk * E;
+    for (long long pix = (long long)blockIdx.x * rpp + rloc; pix < P; pix += (long long)gridDim.x * rpp) {
+      Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(dy + pix * lddy + c0);
+      Vec16<T> yo;
+      if (relu) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
+      Vec16<T> z;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float dz = am_to_f32(g.v[e]);
+        if (relu && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+        s[e] += dz;
+        z.v[e] = am_from_f32<T>(dz);
+      }
+      if (dz_out) *reinterpret_cast<Vec16<T>*>(dz_out + pix * lddz + c0) = z;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) red[tid * E + e] = s[e];
+  __syncthreads();
+  if (dbias) {
+    for (int ce = tid; ce < cpr * E; ce += 256) {
+      const int ch = ce / E, e = ce % E;
+      float a = 0.f;
+      for (int r = 0; r < rpp; ++r) a += red[(r * cpr + ch) * E + e];
+      if (ce < Cvalid) atomicAdd(dbias + ce, a * gscale);
+    }
+  }
+}
+
+inline int ew_grid(long long total_threads) {
+  long long b = (total_threads + 255) / 256;
+  if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int am_bn_finalize(const double* stats, int nrep, double count, const float* conv_bias, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int training, float* scale, float* shift, float* save_mean, float* save_rstd, int C,
+                              am_stream_t stream) {
+  if (C <= 0 || !scale || !shift) return AM_ERR_ARG;
+  if (training && (!stats || count <= 0.0)) return AM_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return AM_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), stats, nrep, count,
+                     conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
+                     save_rstd, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+#define AM_EW_CHECK(C, ld, es) (((C) * (es)) % 16 != 0 || ((ld) * (es)) % 16 != 0)
+
+extern "C" int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
+                           int relu, void* y, int ldy, long long P, int C, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((dtype != AM_F16 && dtype != AM_F32) || !x || !y || !scale || !shift || P < 0 || C <= 0) return AM_ERR_ARG;
+  if (AM_EW_CHECK(C, ldx, es) || (ldy * es) % 16 != 0 || (res && (ldr * es) % 16 != 0)) return AM_ERR_ARG;
+  if (P == 0) return AM_OK;
+  const int grid = ew_grid(P * (C * es / 16));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16)
+    hipLaunchKernelGGL(bn_apply_k<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, scale, shift, (const half_t*)res, ldr, relu, (half_t*)y, ldy, P, C);
+  else
+    hipLaunchKernelGGL(bn_apply_k<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, scale, shift, (const float*)res, ldr, relu, (float*)y, ldy, P, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                                const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
+                                am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((dtype != AM_F16 && dtype != AM_F32) || !dy || !x || !mean || !rstd || !sums || (relu && !yout) || C <= 0) return AM_ERR_ARG;
+  if (AM_EW_CHECK(C, ldx, es) || (lddy * es) % 16 != 0 || (relu && (ldyo * es) % 16 != 0)) return AM_ERR_ARG;
+  const int E = 16 / es, cpr = C / E;
+  if (cpr > 256) return AM_ERR_UNSUPPORTED;
+  if (P == 0) return AM_OK;
+  const int rpp = 256 / cpr;
+  int grid = (int)((P + rpp * 8 - 1) / (rpp * 8));
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const size_t lds = 256 * 2 * E * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16)
+    hipLaunchKernelGGL(bn_bwd_reduce_k<half_t>, dim3(grid), dim3(256), lds, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, relu, sums, P, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(grid), dim3(256), lds, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, relu, sums, P, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bn_bwd_finalize(const double* sums, int nrep, double count, const float* gamma, const float* rstd,
+                                  float gscale, float* dgamma, float* dbeta, float* coef, int C, am_stream_t stream) {
+  if (!sums || !rstd || !coef || C <= 0 || count <= 0.0) return AM_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), sums, nrep, count, gamma, rstd, gscale, dgamma, dbeta, coef, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                               const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
+                               void* dz_out, int lddz, long long P, int C, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((dtype != AM_F16 && dtype != AM_F32) || !dy || !x || !mean || !rstd || !coef || !dx || (relu && !yout) || C <= 0) return AM_ERR_ARG;
+  if (AM_EW_CHECK(C, ldx, es) || (lddy * es) % 16 != 0 || (lddx * es) % 16 != 0 || (relu && (ldyo * es) % 16 != 0) || (dz_out && (lddz * es) % 16 != 0)) return AM_ERR_ARG;
+  if (P == 0) return AM_OK;
+  const int grid = ew_grid(P * (C * es / 16));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16)
+    hipLaunchKernelGGL(bn_bwd_apply_k<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, coef, relu, (half_t*)dx, lddx, (half_t*)dz_out, lddz, P, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, coef, relu, (float*)dx, lddx, (float*)dz_out, lddz, P, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bias_relu_bwd(int dtype, const void* dy, int lddy, const void* yout, int ldyo, int relu, void* dz_out,
+                                int lddz, float* dbias, float gscale, long long P, int C, int Cvalid, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((dtype != AM_F16 && dtype != AM_F32) || !dy || (relu && !yout) || C <= 0 || Cvalid > C) return AM_ERR_ARG;
+  if ((C * es) % 16 != 0 || (lddy * es) % 16 != 0 || (relu && (ldyo * es) % 16 != 0) || (dz_out && (lddz * es) % 16 != 0)) return AM_ERR_ARG;
+  const int E = 16 / es, cpr = C / E;
+  if (cpr > 256) return AM_ERR_UNSUPPORTED;
+  if (P == 0) return AM_OK;
+  const int rpp = 256 / cpr;
+  int grid = (int)((P + rpp * 8 - 1) / (rpp * 8));
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const size_t lds = 256 * E * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16)
+    hipLaunchKernelGGL(bias_relu_bwd_k<half_t>, dim3(grid), dim3(256), lds, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, relu, (half_t*)dz_out, lddz, dbias, gscale, P, C, Cvalid);
+  else
+    hipLaunchKernelGGL(bias_relu_bwd_k<float>, dim3(grid), dim3(256), lds, s, (const float*)dy, lddy, (const float*)yout, ldyo, relu, (float*)dz_out, lddz, dbias, gscale, P, C, Cvalid);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

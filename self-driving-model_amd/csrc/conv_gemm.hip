@@ -1,0 +1,499 @@
+// Convolution as implicit GEMM on gfx950 matrix cores: forward / dgrad ("gather-GEMM") and wgrad.
+//
+// Data layout in HBM: activations NHWC (pixel-major, channels contiguous), packed weights
+// [N][taps][run] (k contiguous).  A "tap" gathers one contiguous run of `krun` elements per output
+// row, so every A-operand row of a K-step is one 64-byte slab of one input pixel (or of 8 adjacent
+// pixels for the 3-channel first layers).  Zero padding = slabs whose pixel is outside the image.
+//
+// Forward/dgrad kernel: BM x BN output tile per 256-thread workgroup (4 waves), K-step 64 bytes,
+// register-staged global->LDS double buffer (one barrier per K-step), LDS rows padded to 80 B so
+// ds_read_b128 fragment reads are conflict-free, MFMA 32x32x16 f16 (or exact-f32 32x32x2) with
+// fp32 accumulators.  Epilogue: BatchNorm batch statistics (per-channel sum / sum of squares of
+// the accumulator, fp64 atomics into 16 replicas), bias, ReLU, store.
+//
+// Wgrad kernel: both operands are pixel-major, the reduction runs over pixels, so fragments are
+// read from LDS with the hardware transpose read ds_read_b64_tr_b16 (f16) or plain b32 (f32).
+// Split over pixel chunks, fp32 atomic accumulation into dW.
+#include "am_common.h"
+
+namespace {
+
+struct ConvKParams {
+  am_conv_geom g;
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  double* stats;
+  int M, nk, ksteps_per_tap, Ktot, relu, mtiles, ntiles;
+};
+
+struct RowInfo {
+  int img;  // image index, -1 when the row is past M
+  int iy0, ix0;
+};
+
+__device__ __forceinline__ void decode_row(const am_conv_geom& g, int m, int M, RowInfo& r, int& opix) {
+  if (m < M) {
+    const int hw = g.MH * g.MW;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int my = rem / g.MW;
+    const int mx = rem - my * g.MW;
+    r.img = img;
+    r.iy0 = my * g.iys;
+    r.ix0 = mx * g.ixs;
+    opix = (img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0;
+  } else {
+    r.img = -1;
+    r.iy0 = r.ix0 = 0;
+    opix = -1;
+  }
+}
+
+// 16-byte slab chunk of the gathered operand: row `r`, tap offsets (dy,dx), element offset `roff`
+// inside the run.  Out-of-image pixels read as zero.
+template <typename T>
+__device__ __forceinline__ uint4 gather_chunk(const am_conv_geom& g, const T* __restrict__ x, const RowInfo& r,
+                                              int dy, int dx, int roff) {
+  const int iy = r.iy0 + dy;
+  const int ixb = r.ix0 + dx;
+  const int ix = ixb + (roff >> g.pix_shift);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (r.img >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) {
+    const long long pix = (long long)(r.img * g.IH + iy) * g.IW + ixb;
+    v = *reinterpret_cast<const uint4*>(x + pix * g.ldi + g.x_coff + roff);
+  }
+  return v;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 64 / (int)sizeof(T);   // elements per K-step
+  constexpr int PITCH = 80;                 // LDS row pitch in bytes (64 + 16 pad)
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AR = BM / 64;
+  constexpr int BCH = (BN * 4 + 255) / 256;
+  constexpr int STAGE = (BM + BN) * PITCH;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* opix_s = reinterpret_cast<int*>(smem + 2 * STAGE);
+
+  const am_conv_geom& g = p.g;
+  const T* __restrict__ x = static_cast<const T*>(p.x);
+  const T* __restrict__ w = static_cast<const T*>(p.w);
+  T* __restrict__ y = static_cast<T*>(p.y);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lb = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = lb / p.ntiles, nt = lb - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int chunk = tid & 3;
+
+  RowInfo rows[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int dummy;
+    decode_row(g, m0 + (tid >> 2) + 64 * i, p.M, rows[i], dummy);
+  }
+  for (int r = tid; r < BM; r += 256) {
+    RowInfo tmp;
+    int op;
+    decode_row(g, m0 + r, p.M, tmp, op);
+    opix_s[r] = op;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  uint4 ra[AR], rb0, rb1;
+  static_assert(BCH <= 2, "B tile loader handles at most 128 rows");
+
+  auto load_tile = [&](int kk) {
+    const int tap = kk / p.ksteps_per_tap;
+    const int roff = (kk - tap * p.ksteps_per_tap) * BK + chunk * EPC;
+    const int dy = g.dy[tap], dx = g.dx[tap];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) ra[i] = gather_chunk<T>(g, x, rows[i], dy, dx, roff);
+    {
+      // BN*4 chunks per K-step; when BN*4 < 256 the upper threads re-read a valid row (never stored)
+      const T* wk = w + (size_t)kk * BK + (tid & 3) * EPC;
+      rb0 = *reinterpret_cast<const uint4*>(wk + (size_t)(n0 + ((tid % (BN * 4)) >> 2)) * p.Ktot);
+      if constexpr (BCH > 1) rb1 = *reinterpret_cast<const uint4*>(wk + (size_t)(n0 + 64 + (tid >> 2)) * p.Ktot);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* As = smem + stage * STAGE;
+    char* Bs = As + BM * PITCH;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(As + ((tid >> 2) + 64 * i) * PITCH + chunk * 16) = ra[i];
+    if (BN * 4 >= 256 || tid < BN * 4) *reinterpret_cast<uint4*>(Bs + (tid >> 2) * PITCH + (tid & 3) * 16) = rb0;
+    if constexpr (BCH > 1) *reinterpret_cast<uint4*>(Bs + (64 + (tid >> 2)) * PITCH + (tid & 3) * 16) = rb1;
+  };
+
+  if (p.nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kk = 0; kk < p.nk; ++kk) {
+    const int stage = kk & 1;
+    if (kk + 1 < p.nk) load_tile(kk + 1);
+    const char* As = smem + stage * STAGE + (wm * TM * 32 + (lane & 31)) * PITCH;
+    const char* Bs = smem + stage * STAGE + BM * PITCH + (wn * TN * 32 + (lane & 31)) * PITCH;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8_t a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const half8_t*>(As + t * 32 * PITCH + ks * 32 + (lane >> 5) * 16);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const half8_t*>(Bs + t * 32 * PITCH + ks * 32 + (lane >> 5) * 16);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const float*>(As + t * 32 * PITCH + (ks * 2 + (lane >> 5)) * 4);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const float*>(Bs + t * 32 * PITCH + (ks * 2 + (lane >> 5)) * 4);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+    if (kk + 1 < p.nk) store_tile(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: BN statistics (pre-bias accumulator), bias, ReLU, store ----
+  if (p.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; stage buffers are free after the last barrier
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        const int col = wn * TN * 32 + tn * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = s;
+        red[(wm * BN + col) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        s += (double)red[(a * BN + tid) * 2 + 0];
+        q += (double)red[(a * BN + tid) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)(lb % AM_STATS_REPLICAS) * 2 * g.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + g.N + n0 + tid, q);
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+    const bool colok = col < g.N;
+    const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int op = opix_s[row];
+        float v = acc[tm][tn][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (op >= 0 && colok) y[(size_t)op * g.ldo + g.y_coff + col] = am_from_f32<T>(v);
+      }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_conv(const ConvKParams& p, hipStream_t s) {
+  constexpr int STAGE = (BM + BN) * 80;
+  ConvKParams q = p;
+  q.mtiles = am_cdiv(p.M, BM);
+  q.ntiles = am_cdiv(p.g.N, BN);
+  const size_t lds = 2 * STAGE + BM * sizeof(int);
+  hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN>), dim3(q.mtiles * q.ntiles), dim3(256), lds, s, q);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+template <typename T>
+int dispatch_conv(const ConvKParams& p, hipStream_t s) {
+  if (p.g.N > 64) return launch_conv<T, 128, 128, 2, 2>(p, s);
+  if (p.g.N > 32) return launch_conv<T, 256, 64, 4, 1>(p, s);
+  return launch_conv<T, 256, 32, 4, 1>(p, s);
+}
+
+int check_geom(const am_conv_geom* g, int dtype) {
+  if (!g || (dtype != AM_F32 && dtype != AM_F16)) return AM_ERR_ARG;
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (g->ntaps < 0 || g->ntaps > AM_MAX_TAPS || g->N <= 0 || g->B < 0) return AM_ERR_ARG;
+  if (g->krun <= 0 || (g->krun * es) % 64 != 0) return AM_ERR_ARG;
+  if ((g->ldi * es) % 16 != 0 || (g->x_coff * es) % 16 != 0) return AM_ERR_ARG;
+  if (g->pix_shift < 0 || g->pix_shift > 31) return AM_ERR_ARG;
+  if ((long long)g->B * g->MH * g->MW > 0x7fffffffLL || (long long)g->B * g->OH * g->OW > 0x7fffffffLL) return AM_ERR_ARG;
+  return AM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// wgrad
+// --------------------------------------------------------------------------------------------
+struct WgradParams {
+  am_conv_geom g;
+  const void* x;
+  const void* dy;
+  float* dw;
+  float scale;
+  int M, nk, ksteps_per_tap, Ktot, ktiles, ntiles, mchunks, mc;
+};
+
+template <typename T, int BNO, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 64 / (int)sizeof(T);  // elements per 64-byte slab
+  constexpr int BKC = NS * BK;             // k-columns per tile
+  constexpr int PS = sizeof(T) == 2 ? 64 : 32;  // pixels per step
+  constexpr int DYB = BNO * (int)sizeof(T);     // dY row bytes
+  constexpr int PDY = DYB + 64;                 // pitches == 64 (mod 256): conflict-free transposed reads
+  constexpr int PX = NS * 64 + 64;
+  constexpr int TMN = BNO / 2 / 32, TNK = BKC / 2 / 32;
+  constexpr int DCH = DYB / 16 / 4;  // dY chunks per thread (4 threads per pixel row)
+  static_assert(TMN >= 1 && TNK >= 1, "tile too small");
+  static_assert(PDY % 128 == 64 && PX % 128 == 64, "pitch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;
+  char* Xs = smem + PS * PDY;
+
+  const am_conv_geom& g = p.g;
+  const T* __restrict__ x = static_cast<const T*>(p.x);
+  const T* __restrict__ dy = static_cast<const T*>(p.dy);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1;
+  const int tiles = p.ktiles * p.ntiles;
+  const int lb = xcd_remap(blockIdx.x, tiles * p.mchunks);
+  const int mcid = lb / tiles;
+  const int tile = lb - mcid * tiles;
+  const int nt = tile / p.ktiles, kt = tile - nt * p.ktiles;
+  const int n0 = nt * BNO, kk0 = kt * NS;
+  const int mbeg = mcid * p.mc;
+  const int mend = min(p.M, mbeg + p.mc);
+
+  // slab -> tap geometry (fixed per block)
+  int s_dy[NS], s_dx[NS], s_roff[NS];
+  bool s_ok[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kk = kk0 + s;
+    s_ok[s] = kk < p.nk;
+    const int tap = s_ok[s] ? kk / p.ksteps_per_tap : 0;
+    s_dy[s] = g.dy[tap];
+    s_dx[s] = g.dx[tap];
+    s_roff[s] = (kk - tap * p.ksteps_per_tap) * BK + (tid & 3) * EPC;
+  }
+
+  f32x16 acc[TMN][TNK];
+#pragma unroll
+  for (int a = 0; a < TMN; ++a)
+#pragma unroll
+    for (int b = 0; b < TNK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // PS*4 loader threads per step: thread -> pixel row (tid>>2), 16-byte lane (tid&3)
+  const bool loader = (tid >> 2) < PS;
+  uint4 rdy[DCH], rx[NS];
+
+  auto load_step = [&](int mstep) {
+    if (!loader) return;
+    RowInfo ri;
+    int op;
+    const int m = mstep + (tid >> 2);
+    decode_row(g, m, mend, ri, op);
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const int c = (tid & 3) + 4 * i;  // chunk inside the dY row
+      const int n = n0 + c * EPC;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (op >= 0 && n < g.N) v = *reinterpret_cast<const uint4*>(dy + (size_t)op * g.ldo + g.y_coff + n);
+      rdy[i] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) rx[s] = s_ok[s] ? gather_chunk<T>(g, x, ri, s_dy[s], s_dx[s], s_roff[s]) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto store_step = [&]() {
+    if (!loader) return;
+    const int r = tid >> 2;
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) *reinterpret_cast<uint4*>(dYs + r * PDY + ((tid & 3) + 4 * i) * 16) = rdy[i];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(Xs + r * PX + s * 64 + (tid & 3) * 16) = rx[s];
+  };
+
+  if (mbeg < mend) load_step(mbeg);
+  for (int ms = mbeg; ms < mend; ms += PS) {
+    __syncthreads();  // previous step's fragment reads are done
+    store_step();
+    __syncthreads();
+    if (ms + PS < mend) load_step(ms + PS);
+    if constexpr (sizeof(T) == 2) {
+      const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+      for (int ks = 0; ks < PS / 16; ++ks) {
+        half8_t a[TMN], b[TNK];
+        const int prow = ks * 16 + 8 * (gq >> 1) + q;
+#pragma unroll
+        for (int t = 0; t < TMN; ++t) {
+          const char* base = dYs + prow * PDY + ((wn * TMN + t) * 32 + (gq & 1) * 16 + 4 * pp) * 2;
+          s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base));
+          s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 4 * PDY));
+          half4_t l4 = __builtin_bit_cast(half4_t, lo), h4 = __builtin_bit_cast(half4_t, hi);
+          a[t] = half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < TNK; ++t) {
+          const char* base = Xs + prow * PX + ((wk * TNK + t) * 32 + (gq & 1) * 16 + 4 * pp) * 2;
+          s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base));
+          s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 4 * PX));
+          half4_t l4 = __builtin_bit_cast(half4_t, lo), h4 = __builtin_bit_cast(half4_t, hi);
+          b[t] = half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+        }
+#pragma unroll
+        for (int tm = 0; tm < TMN; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < PS / 2; ++ks) {
+        float a[TMN], b[TNK];
+        const int prow = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < TMN; ++t) a[t] = *reinterpret_cast<const float*>(dYs + prow * PDY + ((wn * TMN + t) * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int t = 0; t < TNK; ++t) b[t] = *reinterpret_cast<const float*>(Xs + prow * PX + ((wk * TNK + t) * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int tm = 0; tm < TMN; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+
+  // flush: fp32 atomics, rows = output channel n, cols = packed k
+#pragma unroll
+  for (int tn = 0; tn < TNK; ++tn) {
+    const int kc = kk0 * BK + (wk * TNK + tn) * 32 + (lane & 31);
+    if (kc >= p.Ktot) continue;
+#pragma unroll
+    for (int tm = 0; tm < TMN; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (wn * TMN + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < g.N) atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+      }
+  }
+}
+
+template <typename T, int BNO, int NS>
+int launch_wgrad(const WgradParams& p0, hipStream_t s) {
+  constexpr int PS = sizeof(T) == 2 ? 64 : 32;
+  constexpr int PDY = BNO * (int)sizeof(T) + 64, PX = NS * 64 + 64;
+  WgradParams p = p0;
+  p.ktiles = am_cdiv(p.nk, NS);
+  p.ntiles = am_cdiv(p.g.N, BNO);
+  const int tiles = p.ktiles * p.ntiles;
+  // aim for ~1024 workgroups (4 per CU); each pixel chunk a multiple of the step
+  int mchunks = 1024 / tiles;
+  if (mchunks < 1) mchunks = 1;
+  int mc = am_cdiv(p.M, mchunks);
+  mc = am_cdiv(mc, PS * 4) * PS * 4;  // at least 4 steps per chunk
+  p.mc = mc;
+  p.mchunks = am_cdiv(p.M, mc);
+  const size_t lds = (size_t)PS * (PDY + PX);
+  hipLaunchKernelGGL((conv_wgrad_k<T, BNO, NS>), dim3(tiles * p.mchunks), dim3(256), lds, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+}  // namespace
+
+extern "C" int am_conv_npad(int N) {
+  if (N > 64) return am_cdiv(N, 128) * 128;
+  if (N > 32) return 64;
+  return 32;
+}
+
+extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w, const float* bias,
+                            int relu, void* y, double* stats, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!y || (g->ntaps > 0 && (!x || !w))) return AM_ERR_ARG;
+  const int es = dtype == AM_F16 ? 2 : 4;
+  ConvKParams p;
+  p.g = *g;
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.stats = stats;
+  p.M = g->B * g->MH * g->MW;
+  if (p.M == 0) return AM_OK;
+  p.ksteps_per_tap = g->krun * es / 64;
+  p.nk = g->ntaps * p.ksteps_per_tap;
+  p.Ktot = g->ntaps * g->krun;
+  p.relu = relu;
+  p.mtiles = p.ntiles = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AM_F16 ? dispatch_conv<half_t>(p, s) : dispatch_conv<float>(p, s);
+}
+
+extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale,
+                             float* dw, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !dy || !dw || g->ntaps <= 0) return AM_ERR_ARG;
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((g->ldo * es) % 16 != 0 || (g->y_coff * es) % 16 != 0) return AM_ERR_ARG;
+  WgradParams p;
+  p.g = *g;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+  p.M = g->B * g->MH * g->MW;
+  if (p.M == 0) return AM_OK;
+  p.ksteps_per_tap = g->krun * es / 64;
+  p.nk = g->ntaps * p.ksteps_per_tap;
+  p.Ktot = g->ntaps * g->krun;
+  p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16) {
+    if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s);
+    return launch_wgrad<half_t, 64, 4>(p, s);
+  }
+  return launch_wgrad<float, 64, 4>(p, s);
+}

@@ -1,0 +1,367 @@
+// The "MoE tail": extractor / context / gating / policy-head MLP arithmetic.  All fp32: the batch is
+// the row count (M <= 64 per GPU), so these layers are weight-bandwidth / latency bound, not MFMA
+// work.  Wave-per-column GEMV batches, wave-per-row LayerNorm and gate softmax-combine, with wave64
+// shuffle reductions.
+#include "am_common.h"
+
+namespace {
+
+constexpr int MB = 8;  // rows per pass
+
+// y[m][n] = act(sum_k x[m][k] * W[n][k] + b[n]); one wave per output column n
+__global__ __launch_bounds__(256) void linear_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int ldy, int M, int N,
+                                                    int K, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* w = W + (size_t)n * K;
+  const float b = bias ? bias[n] : 0.f;
+  for (int m0 = 0; m0 < M; m0 += MB) {
+    float acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = w[k];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+        if (m0 + i < M) acc[i] += wv * x[(size_t)(m0 + i) * ldx + k];
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const float s = wave_sum(acc[i]);
+      if (lane == 0 && m0 + i < M) {
+        float v = s + b;
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)(m0 + i) * ldy + n] = v;
+      }
+    }
+  }
+}
+
+// dx[m][k] (+)= sum_n dz[m][n] * W[n][k], dz = dy * (yact > 0) when yact given.
+// block = 64 k-columns x 4 n-slices; grid (ceil(K/64), ceil(M/MB))
+__global__ __launch_bounds__(256) void linear_bwd_input_k(const float* __restrict__ dy, int lddy, const float* __restrict__ yact,
+                                                          int ldya, const float* __restrict__ W, float* __restrict__ dx, int lddx,
+                                                          int M, int N, int K, int accumulate) {
+  __shared__ float red[4][MB][64];
+  const int kx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx;
+  const int m0 = blockIdx.y * MB;
+  float acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+  const int nper = (N + 3) / 4;
+  const int nb = slice * nper, ne = min(N, nb + nper);
+  if (k < K) {
+    for (int n = nb; n < ne; ++n) {
+      const float wv = W[(size_t)n * K + k];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        if (m0 + i < M) {
+          float g = dy[(size_t)(m0 + i) * lddy + n];
+          if (yact && !(yact[(size_t)(m0 + i) * ldya + n] > 0.f)) g = 0.f;
+          acc[i] += g * wv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MB; ++i) red[slice][i][kx] = acc[i];
+  __syncthreads();
+  if (slice == 0 && k < K) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      if (m0 + i < M) {
+        const float v = (red[0][i][kx] + red[1][i][kx]) + (red[2][i][kx] + red[3][i][kx]);
+        float* d = dx + (size_t)(m0 + i) * lddx + k;
+        *d = accumulate ? *d + v : v;
+      }
+    }
+  }
+}
+
+// dW[n][k] += sum_m dz[m][n] * x[m][k]; dbias[n] += sum_m dz[m][n].  thread per (n,k)
+__global__ __launch_bounds__(256) void linear_bwd_weight_k(const float* __restrict__ dy, int lddy, const float* __restrict__ yact,
+                                                           int ldya, const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                                           float* __restrict__ dbias, int M, int N, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (k >= K) return;
+  float acc = 0.f, bacc = 0.f;
+  for (int m = 0; m < M; ++m) {
+    float g = dy[(size_t)m * lddy + n];
+    if (yact && !(yact[(size_t)m * ldya + n] > 0.f)) g = 0.f;
+    acc += g * x[(size_t)m * ldx + k];
+    bacc += g;
+  }
+  dW[(size_t)n * K + k] += acc;
+  if (dbias && k == 0) dbias[n] += bacc;
+}
+
+// ---- LayerNorm over the last dim (D <= 4096), one wave per row -----------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (size_t)m * ldx;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += xr[d];
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int d = lane; d < D; d += 64) { const float t = xr[d] - mu; q += t * t; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  for (int d = lane; d < D; d += 64) y[(size_t)m * ldy + d] = (xr[d] - mu) * rs * gamma[d] + beta[d];
+  if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_x_k(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dx, int lddx, int M,
+                                                         int D) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float mu = mean[m], rs = rstd[m];
+  float a = 0.f, b = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float g = dy[(size_t)m * lddy + d] * gamma[d];
+    a += g;
+    b += g * (x[(size_t)m * ldx + d] - mu) * rs;
+  }
+  a = wave_sum(a) / (float)D;
+  b = wave_sum(b) / (float)D;
+  for (int d = lane; d < D; d += 64) {
+    const float g = dy[(size_t)m * lddy + d] * gamma[d];
+    const float xh = (x[(size_t)m * ldx + d] - mu) * rs;
+    dx[(size_t)m * lddx + d] = rs * (g - a - xh * b);
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_p_k(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float g = dy[(size_t)m * lddy + d];
+    a += g * (x[(size_t)m * ldx + d] - mean[m]) * rstd[m];
+    b += g;
+  }
+  dgamma[d] += a;
+  dbeta[d] += b;
+}
+
+// ---- gate: weights from logits (softmax/temperature, or sigmoid-normalise; optional top-k mask)
+//      and combined = sum_e w[:,e] * P_e        (models/gating/gating_network.py:149-166) ----------
+struct GatePtrs {
+  const float* p[AM_MAX_EXPERTS];
+  float* dp[AM_MAX_EXPERTS];
+};
+
+__device__ __forceinline__ void gate_weights_row(const float* lg, int E, float temp, int use_softmax, int topk, float* w,
+                                                 float* sig) {
+  float l[AM_MAX_EXPERTS];
+  bool keep[AM_MAX_EXPERTS];
+  for (int e = 0; e < E; ++e) { l[e] = lg[e]; keep[e] = true; }
+  if (topk > 0 && topk < E) {
+    // torch.topk: k largest, ties -> lower index first
+    for (int e = 0; e < E; ++e) {
+      int rank = 0;
+      for (int j = 0; j < E; ++j)
+        if (l[j] > l[e] || (l[j] == l[e] && j < e)) ++rank;
+      keep[e] = rank < topk;
+    }
+  }
+  if (use_softmax) {
+    float mx = -INFINITY;
+    for (int e = 0; e < E; ++e) if (keep[e]) mx = fmaxf(mx, l[e] / temp);
+    float se = 0.f;
+    for (int e = 0; e < E; ++e) { w[e] = keep[e] ? expf(l[e] / temp - mx) : 0.f; se += w[e]; }
+    for (int e = 0; e < E; ++e) w[e] /= se;
+  } else {
+    float ss = 0.f;
+    for (int e = 0; e < E; ++e) { sig[e] = keep[e] ? 1.f / (1.f + expf(-l[e])) : 0.f; ss += sig[e]; }
+    for (int e = 0; e < E; ++e) w[e] = sig[e] / (ss + 1e-8f);
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_combine_fwd_k(const float* __restrict__ logits, GatePtrs ptrs, int ldp, float temp,
+                                                          int use_softmax, int topk, float* __restrict__ weights,
+                                                          float* __restrict__ combined, int B, int E, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float w[AM_MAX_EXPERTS], sig[AM_MAX_EXPERTS];
+  gate_weights_row(logits + (size_t)b * E, E, temp, use_softmax, topk, w, sig);
+  if (lane < E) weights[(size_t)b * E + lane] = w[lane];
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;  // accumulated in expert order into an fp32 zero, as the reference does (:163-166)
+    for (int e = 0; e < E; ++e) acc += w[e] * ptrs.p[e][(size_t)b * ldp + d];
+    combined[(size_t)b * D + d] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_combine_bwd_k(const float* __restrict__ logits, GatePtrs ptrs, int ldp, float temp,
+                                                          int use_softmax, int topk, const float* __restrict__ dcombined,
+                                                          const float* __restrict__ dweights_ext, float* __restrict__ dlogits,
+                                                          int B, int E, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float w[AM_MAX_EXPERTS], sig[AM_MAX_EXPERTS], dw[AM_MAX_EXPERTS];
+  gate_weights_row(logits + (size_t)b * E, E, temp, use_softmax, topk, w, sig);
+  for (int e = 0; e < E; ++e) dw[e] = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float g = dcombined[(size_t)b * D + d];
+    for (int e = 0; e < E; ++e) {
+      dw[e] += g * ptrs.p[e][(size_t)b * ldp + d];
+      ptrs.dp[e][(size_t)b * ldp + d] = w[e] * g;
+    }
+  }
+  for (int e = 0; e < E; ++e) {
+    dw[e] = wave_sum(dw[e]);
+    if (dweights_ext) dw[e] += dweights_ext[(size_t)b * E + e];
+  }
+  if (lane == 0) {
+    if (use_softmax) {
+      float dot = 0.f;
+      for (int e = 0; e < E; ++e) dot += w[e] * dw[e];
+      for (int e = 0; e < E; ++e) dlogits[(size_t)b * E + e] = w[e] * (dw[e] - dot) / temp;
+    } else {
+      float ss = 1e-8f, dot = 0.f;
+      for (int e = 0; e < E; ++e) ss += sig[e];
+      for (int e = 0; e < E; ++e) dot += dw[e] * sig[e];
+      // w_j = s_j / S  ->  dL/ds_e = dw_e / S - dot / S^2 ; ds/dl = s (1 - s); masked (top-k) entries have s = 0
+      for (int e = 0; e < E; ++e) dlogits[(size_t)b * E + e] = (dw[e] / ss - dot / (ss * ss)) * sig[e] * (1.f - sig[e]);
+    }
+  }
+}
+
+// ---- dropout: counter-based hash RNG (statistically equivalent to torch's, not the same stream) ----
+__device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_k(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                                     long long n, float p, unsigned long long seed) {
+  const float inv = 1.f / (1.f - p);
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const bool keep = hash_u32(seed, (unsigned long long)i) >= thr;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * inv : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_k(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                     float* __restrict__ dx, long long n, float p) {
+  const float inv = 1.f / (1.f - p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+inline int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int am_linear_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int M, int N,
+                             int K, int relu, am_stream_t stream) {
+  if (!x || !W || !y || M < 0 || N <= 0 || K <= 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  hipLaunchKernelGGL(linear_fwd_k, dim3(am_cdiv(N, 4)), dim3(256), 0, ST(stream), x, ldx, W, bias, y, ldy, M, N, K, relu);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_linear_bwd_input(const float* dy, int lddy, const float* yact, int ldya, const float* W, float* dx, int lddx,
+                                   int M, int N, int K, int accumulate, am_stream_t stream) {
+  if (!dy || !W || !dx || M < 0 || N <= 0 || K <= 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  hipLaunchKernelGGL(linear_bwd_input_k, dim3(am_cdiv(K, 64), am_cdiv(M, MB)), dim3(256), 0, ST(stream), dy, lddy, yact, ldya, W, dx, lddx, M, N, K, accumulate);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_linear_bwd_weight(const float* dy, int lddy, const float* yact, int ldya, const float* x, int ldx, float* dW,
+                                    float* dbias, int M, int N, int K, am_stream_t stream) {
+  if (!dy || !x || !dW || M < 0 || N <= 0 || K <= 0 || N > 65535) return AM_ERR_ARG;
+  hipLaunchKernelGGL(linear_bwd_weight_k, dim3(am_cdiv(K, 256), N), dim3(256), 0, ST(stream), dy, lddy, yact, ldya, x, ldx, dW, dbias, M, N, K);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                                float* mean, float* rstd, int M, int D, am_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M < 0 || D <= 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  hipLaunchKernelGGL(layernorm_fwd_k, dim3(am_cdiv(M, 4)), dim3(256), 0, ST(stream), x, ldx, gamma, beta, eps, y, ldy, mean, rstd, M, D);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                                const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int M, int D,
+                                am_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || M < 0 || D <= 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  if (dx) hipLaunchKernelGGL(layernorm_bwd_x_k, dim3(am_cdiv(M, 4)), dim3(256), 0, ST(stream), dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, M, D);
+  if (dgamma && dbeta) hipLaunchKernelGGL(layernorm_bwd_p_k, dim3(am_cdiv(D, 256)), dim3(256), 0, ST(stream), dy, lddy, x, ldx, mean, rstd, dgamma, dbeta, M, D);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gate_combine_fwd(const float* logits, const float* const* processed, int E, int ldp, float temperature,
+                                   int use_softmax, int top_k, float* weights, float* combined, int B, int D,
+                                   am_stream_t stream) {
+  if (!logits || !processed || !weights || !combined || E <= 0 || E > AM_MAX_EXPERTS || D <= 0 || temperature == 0.f) return AM_ERR_ARG;
+  if (B == 0) return AM_OK;
+  GatePtrs ptrs;
+  for (int e = 0; e < AM_MAX_EXPERTS; ++e) { ptrs.p[e] = e < E ? processed[e] : nullptr; ptrs.dp[e] = nullptr; }
+  hipLaunchKernelGGL(gate_combine_fwd_k, dim3(am_cdiv(B, 4)), dim3(256), 0, ST(stream), logits, ptrs, ldp, temperature, use_softmax, top_k, weights, combined, B, E, D);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gate_combine_bwd(const float* logits, const float* const* processed, int E, int ldp, float temperature,
+                                   int use_softmax, int top_k, const float* dcombined, const float* dweights_ext,
+                                   float* dlogits, float* const* dprocessed, int B, int D, am_stream_t stream) {
+  if (!logits || !processed || !dcombined || !dlogits || !dprocessed || E <= 0 || E > AM_MAX_EXPERTS || D <= 0 || temperature == 0.f) return AM_ERR_ARG;
+  if (B == 0) return AM_OK;
+  GatePtrs ptrs;
+  for (int e = 0; e < AM_MAX_EXPERTS; ++e) { ptrs.p[e] = e < E ? processed[e] : nullptr; ptrs.dp[e] = e < E ? dprocessed[e] : nullptr; }
+  hipLaunchKernelGGL(gate_combine_bwd_k, dim3(am_cdiv(B, 4)), dim3(256), 0, ST(stream), logits, ptrs, ldp, temperature, use_softmax, top_k, dcombined, dweights_ext, dlogits, B, E, D);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, unsigned long long seed,
+                              am_stream_t stream) {
+  if (!x || !y || !mask || n < 0 || p < 0.f || p >= 1.f) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  hipLaunchKernelGGL(dropout_fwd_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), x, y, mask, n, p, seed);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, am_stream_t stream) {
+  if (!dy || !dx || !mask || n < 0 || p < 0.f || p >= 1.f) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  hipLaunchKernelGGL(dropout_bwd_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), dy, mask, dx, n, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

@@ -1,0 +1,102 @@
+// Step glue on flat fp32 buffers: global grad-norm, clip + AdamW in one pass.
+// Replaces clip_grad_norm_(max_norm) + AdamW.step() (training/train_bdd100k_ddp.py:98-99,
+// training/train_gating_network.py:103-105) without any host synchronisation: the norm stays on
+// the device and the update kernel reads it from there.
+#include "am_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, long long n, double* __restrict__ acc) {
+  __shared__ double red[4];
+  double s = 0.0;
+  const long long n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0)
+    for (long long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (double)x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// p, g, m, v: flat fp32 [n].  norm_sq: device scalar (sum of squares of ALL grads of the step, may
+// span several flat buffers).  clip_coef = min(1, max_norm / (sqrt(norm_sq) + 1e-6)) as torch's
+// clip_grad_norm_.  A non-finite norm skips the update (fp16 loss-scale overflow) and counts it.
+__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps,
+                                               float weight_decay, float bias_c1, float bias_c2_sqrt, float max_norm,
+                                               const double* __restrict__ norm_sq, int* __restrict__ skipped) {
+  float clip = 1.f;
+  if (norm_sq) {
+    const double ns = norm_sq[0];
+    if (!(ns == ns) || ns > 1.7e308 * 0.5) {  // NaN or inf
+      if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+      return;
+    }
+    if (max_norm > 0.f) {
+      const float coef = max_norm / ((float)sqrt(ns) + 1e-6f);
+      clip = coef < 1.f ? coef : 1.f;
+    }
+  }
+  const float step_size = lr / bias_c1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * weight_decay);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, long long n, float mul, const double* __restrict__ denom) {
+  const float f = denom ? mul / (float)denom[0] : mul;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
+}
+
+inline int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int am_sumsq_accumulate(const float* x, long long n, double* acc, am_stream_t stream) {
+  if (!x || !acc || n < 0) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  hipLaunchKernelGGL(sumsq_k, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST(stream), x, n, acc);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
+                             am_stream_t stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     (float)bc1, (float)sqrt(bc2), max_norm, norm_sq, skipped);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_stream_t stream) {
+  if (!x || n < 0) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  hipLaunchKernelGGL(scale_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), x, n, mul, denom);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

@@ -1,0 +1,492 @@
+// HBM-bound spatial kernels of the expert path: layout conversion, max-pool, global average pool,
+// bilinear upsample, pixel-wise cross-entropy.  All coalesced, 16 B per lane where the layout allows.
+#include "am_common.h"
+
+namespace {
+
+inline int ew_grid(long long total_threads) {
+  long long b = (total_threads + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- NCHW fp32 -> NHWC T with channel padding (zeros) --------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ src, T* __restrict__ dst, int C, long long HW,
+                                                      int ld, long long total_pix, float mul) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, p = i - b * HW;
+    const float* s = src + b * C * HW + p;
+    T* d = dst + i * ld;
+    constexpr int E = 16 / (int)sizeof(T);
+    for (int c0 = 0; c0 < ld; c0 += E) {  // ld is a multiple of E: one 16-byte store per chunk
+      uint4 raw;
+      T* o = reinterpret_cast<T*>(&raw);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(c0 + e < C ? s[(long long)(c0 + e) * HW] * mul : 0.f);
+      *reinterpret_cast<uint4*>(d + c0) = raw;
+    }
+  }
+}
+
+// ---- NHWC T -> NCHW fp32 (first C channels) -------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src, float* __restrict__ dst, int C, long long HW,
+                                                      int ld, long long total, float mul) {
+  // one thread per output element, NCHW order: coalesced writes, strided (L2-absorbed) reads
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % HW;
+    const long long bc = i / HW;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    dst[i] = am_to_f32(src[(b * HW + p) * ld + c]) * mul;
+  }
+}
+
+// ---- max-pool 3x3 stride 2 pad 1, NHWC ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
+                                                     int B, int IH, int IW, int OH, int OW, int C) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int cpr = C / E;
+  const long long total = (long long)B * OH * OW * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    long long t = i / cpr;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float best[E];
+    int bi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy * 2 - 1 + kh;
+      if ((unsigned)iy >= (unsigned)IH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox * 2 - 1 + kw;
+        if ((unsigned)ix >= (unsigned)IW) continue;
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + (((long long)b * IH + iy) * IW + ix) * C + ch * E);
+        const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float f = am_to_f32(v[e]);
+          // first maximum in (kh,kw) scan order wins, NaN propagates (torch max_pool2d)
+          if (first || f > best[e] || f != f) { best[e] = f; bi[e] = kh * 3 + kw; }
+        }
+        first = false;
+      }
+    }
+    uint4 outraw;
+    T* o = reinterpret_cast<T*>(&outraw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(best[e]);
+    const long long ooff = (((long long)b * OH + oy) * OW + ox) * C + ch * E;
+    *reinterpret_cast<uint4*>(y + ooff) = outraw;
+    if (arg) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) arg[ooff + e] = (uint8_t)bi[e];
+    }
+  }
+}
+
+// gather form: every input element sums the (at most 4) windows whose arg-max it is
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
+                                                     int B, int IH, int IW, int OH, int OW, int C) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int cpr = C / E;
+  const long long total = (long long)B * IH * IW * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    long long t = i / cpr;
+    const int ix = (int)(t % IW); t /= IW;
+    const int iy = (int)(t % IH);
+    const int b = (int)(t / IH);
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    // windows oy with oy*2-1+kh == iy, kh in 0..2
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = iy + 1 - kh;
+      if (ty < 0 || (ty & 1)) continue;
+      const int oy = ty >> 1;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tx = ix + 1 - kw;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ox = tx >> 1;
+        if (ox >= OW) continue;
+        const long long ooff = (((long long)b * OH + oy) * OW + ox) * C + ch * E;
+        const uint4 raw = *reinterpret_cast<const uint4*>(dy + ooff);
+        const T* g = reinterpret_cast<const T*>(&raw);
+        uint8_t a[E];
+        if constexpr (E == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + ooff);
+        else *reinterpret_cast<unsigned*>(a) = *reinterpret_cast<const unsigned*>(arg + ooff);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (a[e] == kh * 3 + kw) acc[e] += am_to_f32(g[e]);
+      }
+    }
+    uint4 outraw;
+    T* o = reinterpret_cast<T*>(&outraw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(acc[e]);
+    *reinterpret_cast<uint4*>(dx + i * E) = outraw;
+  }
+}
+
+// ---- global average pool NHWC [B][P][ld] -> fp32 [B][C] -------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gap_nhwc_fwd_k(const T* __restrict__ x, int ld, float* __restrict__ out, int P, int C,
+                                                      int splits) {
+  // grid: B * splits blocks; block reduces rows [s*rows_per, ...) of image b; fp32 atomics into out (pre-zeroed)
+  constexpr int E = 16 / (int)sizeof(T);
+  extern __shared__ float red[];
+  const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const int cpr = C / E;
+  const int rpp = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int tid = threadIdx.x, chunk = tid % cpr, rloc = tid / cpr;
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  const int rows_per = (P + splits - 1) / splits;
+  const int r0 = sp * rows_per, r1 = min(P, r0 + rows_per);
+  if (rloc < rpp) {
+    for (int r = r0 + rloc; r < r1; r += rpp) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(x + ((long long)b * P + r) * ld + chunk * E);
+      const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += am_to_f32(v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) red[tid * E + e] = s[e];
+  __syncthreads();
+  for (int ce = tid; ce < C; ce += 256) {
+    const int ch = ce / E, e = ce % E;
+    float a = 0.f;
+    for (int r = 0; r < rpp; ++r) a += red[(r * cpr + ch) * E + e];
+    atomicAdd(out + (long long)b * C + ce, a / (float)P);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gap_nhwc_bwd_k(const float* __restrict__ dout, T* __restrict__ dx, int ld, int P, int C,
+                                                      long long total, float mul) {
+  // dx[b][p][c] = dout[b][c] * mul / P
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long bp = i / C;
+    const long long b = bp / P;
+    dx[bp * ld + c] = am_from_f32<T>(dout[b * C + c] * mul / (float)P);
+  }
+}
+
+// ---- global average pool over NCHW fp32 planes: [BC][HW] -> [BC] -----------------------------
+__global__ __launch_bounds__(256) void gap_plane_fwd_k(const float* __restrict__ x, float* __restrict__ out, long long HW) {
+  __shared__ float red[4];
+  const long long plane = blockIdx.x;
+  const float4* p4 = reinterpret_cast<const float4*>(x + plane * HW);
+  const long long n4 = HW / 4;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = p4[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (long long i = n4 * 4 + threadIdx.x; i < HW; i += 256) s += x[plane * HW + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[plane] = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void gap_plane_bwd_k(const float* __restrict__ dout, float* __restrict__ dx, long long HW,
+                                                       long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dout[i / HW] / (float)HW;
+}
+
+// ---- bilinear upsample, align_corners=False (F.interpolate semantics) -----------------------
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_k(const T* __restrict__ low, int ld, float* __restrict__ out, int B, int C,
+                                                      int h, int w, int H, int W, float sh, float sw) {
+  // grid-stride over NCHW output; reads of the tiny low-res map hit L1/L2
+  const long long total = (long long)B * C * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    long long t = i / W;
+    const int Y = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(Y, sh, h, y0, y1, ly);
+    src_index(X, sw, w, x0, x1, lx);
+    const T* base = low + (long long)b * h * w * ld + c;
+    const float v00 = am_to_f32(base[((long long)y0 * w + x0) * ld]), v01 = am_to_f32(base[((long long)y0 * w + x1) * ld]);
+    const float v10 = am_to_f32(base[((long long)y1 * w + x0) * ld]), v11 = am_to_f32(base[((long long)y1 * w + x1) * ld]);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    out[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
+// One workgroup per (b, c, low-res row y): accumulates the high-res rows that touch row y.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_k(const float* __restrict__ dout, T* __restrict__ dlow, int ld, int B, int C,
+                                                      int h, int w, int H, int W, float sh, float sw, float mul,
+                                                      const float* __restrict__ dev_scale) {
+  extern __shared__ float bins[];  // [w]
+  const int y = blockIdx.x % h;
+  const int c = (blockIdx.x / h) % C;
+  const int b = blockIdx.x / (h * C);
+  for (int i = threadIdx.x; i < w; i += 256) bins[i] = 0.f;
+  __syncthreads();
+  // candidate high-res rows: those whose y0 or y1 equals y.  Conservative range, exact test inside.
+  int Ylo = (int)floorf(((float)y - 1.f + 0.5f) / sh - 0.5f) - 1;
+  int Yhi = (int)ceilf(((float)y + 1.f + 0.5f) / sh - 0.5f) + 1;
+  if (Ylo < 0) Ylo = 0;
+  if (Yhi > H - 1) Yhi = H - 1;
+  if (y == 0) Ylo = 0;
+  if (y == h - 1) Yhi = H - 1;
+  for (int X = threadIdx.x; X < W; X += 256) {
+    int x0, x1;
+    float lx;
+    src_index(X, sw, w, x0, x1, lx);
+    float a0 = 0.f, a1 = 0.f;
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      int y0, y1;
+      float ly;
+      src_index(Y, sh, h, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == y) wy += 1.f - ly;
+      if (y1 == y) wy += ly;
+      if (wy != 0.f) {
+        const float g = dout[(((long long)b * C + c) * H + Y) * W + X] * wy;
+        a0 += g * (1.f - lx);
+        a1 += g * lx;
+      }
+    }
+    atomicAdd(&bins[x0], a0);
+    atomicAdd(&bins[x1], a1);
+  }
+  __syncthreads();
+  const float m = mul * (dev_scale ? dev_scale[0] : 1.f);
+  for (int i = threadIdx.x; i < w; i += 256) dlow[(((long long)b * h + y) * w + i) * ld + c] = am_from_f32<T>(bins[i] * m);
+}
+
+// ---- pixel-wise cross entropy over NCHW fp32 logits with ignore_index ------------------------
+// fwd: acc[0] += sum of -log softmax[target] over valid pixels (fp64), acc[1] += count
+__global__ __launch_bounds__(256) void ce2d_fwd_k(const float* __restrict__ logits, const long long* __restrict__ target, int C,
+                                                  long long HW, long long total_pix, long long ignore_index,
+                                                  double* __restrict__ acc) {
+  __shared__ double red[2][4];
+  double ls = 0.0, cnt = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = target[i];
+    if (t == ignore_index) continue;
+    const long long b = i / HW, p = i - b * HW;
+    const float* l = logits + b * C * HW + p;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[(long long)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(l[(long long)c * HW] - mx);
+    const float lt = (t >= 0 && t < C) ? l[t * HW] : 0.f;
+    ls += (double)(logf(se) + mx - lt);
+    cnt += 1.0;
+  }
+  ls = wave_sum(ls);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(acc + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// bwd: dlogits = (softmax - onehot) * gout / count   (0 at ignored pixels)
+__global__ __launch_bounds__(256) void ce2d_bwd_k(const float* __restrict__ logits, const long long* __restrict__ target, int C,
+                                                  long long HW, long long total_pix, long long ignore_index,
+                                                  const double* __restrict__ acc, const float* __restrict__ gout,
+                                                  float* __restrict__ dlogits) {
+  const float g = gout[0] / (float)fmax(acc[1], 1.0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = target[i];
+    const long long b = i / HW, p = i - b * HW;
+    const float* l = logits + b * C * HW + p;
+    float* d = dlogits + b * C * HW + p;
+    if (t == ignore_index) {
+      for (int c = 0; c < C; ++c) d[(long long)c * HW] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[(long long)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(l[(long long)c * HW] - mx);
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) {
+      float pr = expf(l[(long long)c * HW] - mx) * inv;
+      if (c == t) pr -= 1.f;
+      d[(long long)c * HW] = pr * g;
+    }
+  }
+}
+
+}  // namespace
+
+#define DT_OK(d) ((d) == AM_F16 || (d) == AM_F32)
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int am_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ld, float mul,
+                               am_stream_t stream) {
+  if (!DT_OK(dtype) || !src || !dst || C > ld || B < 0 || (ld * (dtype == AM_F16 ? 2 : 4)) % 16 != 0) return AM_ERR_ARG;
+  const long long HW = (long long)H * W, total = HW * B;
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(nchw_to_nhwc_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (half_t*)dst, C, HW, ld, total, mul);
+  else hipLaunchKernelGGL(nchw_to_nhwc_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (float*)dst, C, HW, ld, total, mul);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int ld, float mul,
+                               am_stream_t stream) {
+  if (!DT_OK(dtype) || !src || !dst || C > ld || B < 0) return AM_ERR_ARG;
+  const long long HW = (long long)H * W, total = HW * B * C;
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(nhwc_to_nchw_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)src, dst, C, HW, ld, total, mul);
+  else hipLaunchKernelGGL(nhwc_to_nchw_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)src, dst, C, HW, ld, total, mul);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int B, int IH, int IW, int C,
+                                   am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (!DT_OK(dtype) || !x || !y || (C * es) % 16 != 0) return AM_ERR_ARG;
+  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+  const long long total = (long long)B * OH * OW * (C * es / 16);
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C);
+  else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
+                                   am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (!DT_OK(dtype) || !dy || !dx || !argmax || (C * es) % 16 != 0) return AM_ERR_ARG;
+  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+  const long long total = (long long)B * IH * IW * (C * es / 16);
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C);
+  else hipLaunchKernelGGL(maxpool_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gap_nhwc_fwd(int dtype, const void* x, int ld, float* out, int B, int P, int C, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (!DT_OK(dtype) || !x || !out || (C * es) % 16 != 0 || (ld * es) % 16 != 0 || C * es / 16 > 256) return AM_ERR_ARG;
+  if (B == 0 || P == 0) return AM_OK;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C, ST(stream));
+  if (e != hipSuccess) return AM_ERR_LAUNCH;
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > (P + 63) / 64) splits = (P + 63) / 64;
+  const size_t lds = 256 * (16 / es) * sizeof(float);
+  if (dtype == AM_F16) hipLaunchKernelGGL(gap_nhwc_fwd_k<half_t>, dim3(B * splits), dim3(256), lds, ST(stream), (const half_t*)x, ld, out, P, C, splits);
+  else hipLaunchKernelGGL(gap_nhwc_fwd_k<float>, dim3(B * splits), dim3(256), lds, ST(stream), (const float*)x, ld, out, P, C, splits);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gap_nhwc_bwd(int dtype, const float* dout, void* dx, int ld, int B, int P, int C, float mul,
+                               am_stream_t stream) {
+  if (!DT_OK(dtype) || !dout || !dx || C > ld) return AM_ERR_ARG;
+  const long long total = (long long)B * P * C;
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(gap_nhwc_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), dout, (half_t*)dx, ld, P, C, total, mul);
+  else hipLaunchKernelGGL(gap_nhwc_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), dout, (float*)dx, ld, P, C, total, mul);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gap_plane_fwd(const float* x, float* out, long long planes, long long HW, am_stream_t stream) {
+  if (!x || !out || planes < 0 || HW <= 0 || planes > 0x7fffffffLL) return AM_ERR_ARG;
+  if (planes == 0) return AM_OK;
+  hipLaunchKernelGGL(gap_plane_fwd_k, dim3((unsigned)planes), dim3(256), 0, ST(stream), x, out, HW);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gap_plane_bwd(const float* dout, float* dx, long long planes, long long HW, am_stream_t stream) {
+  if (!dout || !dx || planes < 0 || HW <= 0) return AM_ERR_ARG;
+  const long long total = planes * HW;
+  if (total == 0) return AM_OK;
+  hipLaunchKernelGGL(gap_plane_bwd_k, dim3(ew_grid(total)), dim3(256), 0, ST(stream), dout, dx, HW, total);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bilinear_up_fwd(int dtype, const void* low, int ld, float* out, int B, int C, int h, int w, int H, int W,
+                                  am_stream_t stream) {
+  if (!DT_OK(dtype) || !low || !out || C > ld || h <= 0 || w <= 0) return AM_ERR_ARG;
+  const long long total = (long long)B * C * H * W;
+  if (total == 0) return AM_OK;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  if (dtype == AM_F16) hipLaunchKernelGGL(bilinear_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)low, ld, out, B, C, h, w, H, W, sh, sw);
+  else hipLaunchKernelGGL(bilinear_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)low, ld, out, B, C, h, w, H, W, sh, sw);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bilinear_up_bwd(int dtype, const float* dout, void* dlow, int ld, int B, int C, int h, int w, int H, int W,
+                                  float mul, const float* dev_scale, am_stream_t stream) {
+  if (!DT_OK(dtype) || !dout || !dlow || C > ld || h <= 0 || w <= 0) return AM_ERR_ARG;
+  if ((long long)B * C * h == 0) return AM_OK;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const size_t lds = sizeof(float) * (size_t)w;
+  if (dtype == AM_F16) hipLaunchKernelGGL(bilinear_bwd_k<half_t>, dim3(B * C * h), dim3(256), lds, ST(stream), dout, (half_t*)dlow, ld, B, C, h, w, H, W, sh, sw, mul, dev_scale);
+  else hipLaunchKernelGGL(bilinear_bwd_k<float>, dim3(B * C * h), dim3(256), lds, ST(stream), dout, (float*)dlow, ld, B, C, h, w, H, W, sh, sw, mul, dev_scale);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_ce2d_fwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
+                           double* acc2, am_stream_t stream) {
+  if (!logits || !target || !acc2 || C <= 0) return AM_ERR_ARG;
+  hipError_t e = hipMemsetAsync(acc2, 0, 2 * sizeof(double), ST(stream));
+  if (e != hipSuccess) return AM_ERR_LAUNCH;
+  const long long total = HW * B;
+  if (total == 0) return AM_OK;
+  hipLaunchKernelGGL(ce2d_fwd_k, dim3(ew_grid(total)), dim3(256), 0, ST(stream), logits, target, C, HW, total, ignore_index, acc2);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_ce2d_bwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
+                           const double* acc2, const float* grad_out, float* dlogits, am_stream_t stream) {
+  if (!logits || !target || !acc2 || !grad_out || !dlogits || C <= 0) return AM_ERR_ARG;
+  const long long total = HW * B;
+  if (total == 0) return AM_OK;
+  hipLaunchKernelGGL(ce2d_bwd_k, dim3(ew_grid(total)), dim3(256), 0, ST(stream), logits, target, C, HW, total, ignore_index, acc2, grad_out, dlogits);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

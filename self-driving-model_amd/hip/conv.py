@@ -1,0 +1,313 @@
+"""Host side of the conv gather-GEMM: geometry structs, weight packing and the autograd node
+conv (+bias) (+BatchNorm) (+residual) (+ReLU) over NHWC activations.
+
+Internal activation layout: torch tensors [B, H, W, C] (channels contiguous) of the compute dtype
+(torch.float16 or torch.float32).  3-channel images are padded to 16 bytes per pixel.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import AM_F16, AM_F32, AM_STATS_REPLICAS, ConvGeom
+
+
+def _L():
+    return _lib.get()
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float16:
+        return AM_F16
+    if dtype == torch.float32:
+        return AM_F32
+    raise ValueError(f"unsupported compute dtype {dtype}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def require_hip(t: torch.Tensor, what: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} is on {t.device}: the AutoMoE HIP path only runs on an MI355X (HIP) device; "
+                           f"there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
+
+
+def image_channels(dtype: torch.dtype) -> int:
+    """Channel padding of a 3-channel image: 16 bytes per pixel."""
+    return 16 // torch.empty((), dtype=dtype).element_size()
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad: int
+    first: bool = False  # 3-channel input: taps are kernel rows, a run covers 8 pixels
+
+
+def channel_ld(c: int, es: int) -> int:
+    """Pixel stride (elements) of a C-channel NHWC activation: C itself when rows are 16-byte multiples,
+    else padded to a 64-byte multiple (expert heads with 14 / 19 / 3 channels)."""
+    return c if (c * es) % 16 == 0 else ((c * es + 63) // 64) * 64 // es
+
+
+def out_size(n: int, s: ConvSpec) -> int:
+    return (n + 2 * s.pad - s.k) // s.stride + 1
+
+
+def _geom(**kw) -> ConvGeom:
+    g = ConvGeom()
+    dy, dx = kw.pop("dy"), kw.pop("dx")
+    for k, v in kw.items():
+        setattr(g, k, int(v))
+    for i, (a, b) in enumerate(zip(dy, dx)):
+        g.dy[i], g.dx[i] = int(a), int(b)
+    return g
+
+
+def fwd_geom(s: ConvSpec, B: int, IH: int, IW: int, ldi: int, ldo: int, es: int, x_coff: int = 0, y_coff: int = 0) -> ConvGeom:
+    OH, OW = out_size(IH, s), out_size(IW, s)
+    if s.first:
+        cp = 16 // es
+        assert s.k <= 8 and ldi == cp
+        return _geom(B=B, MH=OH, MW=OW, IH=IH, IW=IW, ldi=ldi, x_coff=0, OH=OH, OW=OW, ldo=ldo, y_coff=y_coff,
+                     oys=1, oy0=0, oxs=1, ox0=0, iys=s.stride, ixs=s.stride, ntaps=s.k, krun=8 * cp,
+                     pix_shift=int(math.log2(cp)), N=s.cout, dy=[kh - s.pad for kh in range(s.k)], dx=[-s.pad] * s.k)
+    assert (s.cin * es) % 64 == 0, f"Cin={s.cin} not a multiple of {64 // es}"
+    taps = [(kh - s.pad, kw - s.pad) for kh in range(s.k) for kw in range(s.k)]
+    return _geom(B=B, MH=OH, MW=OW, IH=IH, IW=IW, ldi=ldi, x_coff=x_coff, OH=OH, OW=OW, ldo=ldo, y_coff=y_coff,
+                 oys=1, oy0=0, oxs=1, ox0=0, iys=s.stride, ixs=s.stride, ntaps=len(taps), krun=s.cin, pix_shift=31,
+                 N=s.cout, dy=[t[0] for t in taps], dx=[t[1] for t in taps])
+
+
+def pack_fwd(w: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW fp32 -> [npad][taps*krun] `dtype` (k contiguous)."""
+    O = w.shape[0]
+    npad = _L().am_conv_npad(O)
+    wt = w.detach().permute(0, 2, 3, 1)  # [O, kh, kw, I]
+    if s.first:
+        cp = image_channels(dtype)
+        buf = w.new_zeros(O, s.k, 8, cp)
+        buf[:, :, : s.k, : s.cin] = wt
+        wt = buf
+    out = torch.zeros(npad, wt[0].numel(), dtype=dtype, device=w.device)
+    out[:O] = wt.reshape(O, -1).to(dtype)
+    return out
+
+
+def unpack_wgrad(dwp: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Tensor:
+    """packed fp32 [O][taps*krun] -> OIHW fp32 gradient."""
+    O = s.cout
+    if s.first:
+        cp = image_channels(dtype)
+        g = dwp[:O].reshape(O, s.k, 8, cp)[:, :, : s.k, : s.cin]
+    else:
+        g = dwp[:O].reshape(O, s.k, s.k, s.cin)
+    return g.permute(0, 3, 1, 2).contiguous()
+
+
+def dgrad_plans(s: ConvSpec, B: int, IH: int, IW: int, ld_dx: int, ld_dy: int, es: int):
+    """[(geom, tap list [(kh,kw)])] : one gather-GEMM per output-parity class of the input gradient.
+    dX[n,y,x,ci] = sum_{kh,kw,co} dY[n,(y+p-kh)/s,(x+p-kw)/s,co] * W[co,ci,kh,kw] over taps whose division is exact."""
+    assert not s.first
+    OH, OW = out_size(IH, s), out_size(IW, s)
+    assert (ld_dy * es) % 64 == 0, f"dY pixel stride {ld_dy}: dgrad run must be a multiple of 64 bytes"
+    plans = []
+    st = s.stride
+    for py in range(st):
+        for px in range(st):
+            MH, MW = (IH - py + st - 1) // st, (IW - px + st - 1) // st
+            if MH <= 0 or MW <= 0:
+                continue
+            taps = [(kh, kw) for kh in range(s.k) for kw in range(s.k)
+                    if (py + s.pad - kh) % st == 0 and (px + s.pad - kw) % st == 0]
+            g = _geom(B=B, MH=MH, MW=MW, IH=OH, IW=OW, ldi=ld_dy, x_coff=0, OH=IH, OW=IW, ldo=ld_dx, y_coff=0,
+                      oys=st, oy0=py, oxs=st, ox0=px, iys=1, ixs=1, ntaps=len(taps), krun=ld_dy, pix_shift=31,
+                      N=s.cin, dy=[(py + s.pad - kh) // st for kh, _ in taps], dx=[(px + s.pad - kw) // st for _, kw in taps])
+            plans.append((g, taps))
+    return plans
+
+
+def pack_dgrad(w: torch.Tensor, taps, dtype: torch.dtype, ld_dy: int) -> Optional[torch.Tensor]:
+    """OIHW -> [npad(I)][len(taps)*ld_dy] for one parity class (O zero-padded to the dY pixel stride)."""
+    if not taps:
+        return None
+    O, I = w.shape[0], w.shape[1]
+    npad = _L().am_conv_npad(I)
+    wt = w.detach().permute(1, 2, 3, 0)  # [I, kh, kw, O]
+    sel = torch.stack([wt[:, kh, kw, :] for kh, kw in taps], dim=1)  # [I, T, O]
+    if ld_dy != O:
+        sel = torch.nn.functional.pad(sel, (0, ld_dy - O))
+    out = torch.zeros(npad, sel[0].numel(), dtype=dtype, device=w.device)
+    out[:I] = sel.reshape(I, -1).to(dtype)
+    return out
+
+
+class PackedWeights:
+    """Per-conv cache of packed operands, invalidated when the fp32 master weight is updated."""
+
+    def __init__(self):
+        self.key = None
+        self.fwd = None
+        self.dgrad = {}
+
+    def get_fwd(self, w: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Tensor:
+        from .. import runtime
+        key = (w._version, w.data_ptr(), dtype, runtime.weight_epoch() if w.requires_grad else -1)
+        if key != self.key:
+            self.key, self.fwd, self.dgrad = key, pack_fwd(w, s, dtype), {}
+        return self.fwd
+
+    def get_dgrad(self, w: torch.Tensor, s: ConvSpec, dtype: torch.dtype, idx: int, taps, ld_dy: int) -> Optional[torch.Tensor]:
+        self.get_fwd(w, s, dtype)
+        if idx not in self.dgrad:
+            self.dgrad[idx] = pack_dgrad(w, taps, dtype, ld_dy)
+        return self.dgrad[idx]
+
+
+# ---------------------------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------------------------
+def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None):
+    import ctypes
+    _L().am_conv_gemm(ctypes.byref(g), dt_code(y.dtype), ptr(x), ptr(wp), ptr(bias), int(relu), ptr(y), ptr(stats), stream())
+
+
+def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp):
+    import ctypes
+    _L().am_conv_wgrad(ctypes.byref(g), dt_code(x.dtype), ptr(x), ptr(dy), float(scale), ptr(dwp), stream())
+
+
+class _Cfg:
+    """Static description of one conv(+BN)(+ReLU) layer, shared by forward and backward."""
+
+    def __init__(self, spec: ConvSpec, cache: PackedWeights, bn=None, relu=False, loss_scale=1.0):
+        self.spec, self.cache, self.bn, self.relu, self.loss_scale = spec, cache, bn, relu, loss_scale
+
+
+class ConvBnAct(torch.autograd.Function):
+    """y = act(BN(conv(x, w) + b) + residual), NHWC.  BN in train mode uses batch statistics and
+    updates the running buffers in place (torch.nn.BatchNorm2d semantics); in eval mode the running
+    statistics.  Gradients: x, w, b, gamma, beta, residual."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, residual, cfg: _Cfg, training: bool):
+        require_hip(x, "conv input")
+        s, L = cfg.spec, _L()
+        B, IH, IW, ldi = x.shape
+        es = x.element_size()
+        OH, OW = out_size(IH, s), out_size(IW, s)
+        dtype, dev = x.dtype, x.device
+        cout = s.cout
+        ldo = channel_ld(cout, es)
+        g = fwd_geom(s, B, IH, IW, ldi, ldo, es)
+        wp = cfg.cache.get_fwd(w, s, dtype)
+        bn = cfg.bn
+        alloc = torch.zeros if ldo != cout else torch.empty
+        raw = alloc((B, OH, OW, ldo), dtype=dtype, device=dev)
+        P = B * OH * OW
+        if bn is None:
+            conv_gemm(g, x, wp, b, cfg.relu, raw, None)
+            y, mean, rstd = raw, None, None
+        else:
+            use_batch = training or bn.running_mean is None
+            stats = torch.zeros(AM_STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=dev) if use_batch else None
+            conv_gemm(g, x, wp, b, False, raw, stats)
+            scale = torch.empty(cout, dtype=torch.float32, device=dev)
+            shift = torch.empty_like(scale)
+            mean = torch.empty_like(scale)
+            rstd = torch.empty_like(scale)
+            momentum = bn.momentum if bn.momentum is not None else 0.1
+            upd = use_batch and bn.track_running_stats and bn.running_mean is not None
+            L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), ptr(b) if use_batch else None, ptr(gamma), ptr(beta),
+                             ptr(bn.running_mean) if (upd or not use_batch) else None,
+                             ptr(bn.running_var) if (upd or not use_batch) else None, float(momentum), float(bn.eps),
+                             int(use_batch), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), cout, stream())
+            if upd and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            y = torch.empty_like(raw)
+            L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
+                          residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
+            ctx.use_batch = use_batch
+        ctx.cfg, ctx.geom = cfg, g
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if (cfg.relu or bn is None) else None, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, gamma, raw, y, mean, rstd = ctx.saved_tensors
+        cfg, g, L = ctx.cfg, ctx.geom, _L()
+        s = cfg.spec
+        dtype, dev = x.dtype, x.device
+        es = x.element_size()
+        B, OH, OW, ldo = dy.shape
+        P = B * OH * OW
+        cout = s.cout
+        inv = 1.0 / cfg.loss_scale
+        dy = dy.contiguous()
+        code = dt_code(dtype)
+        db = dgamma = dbeta = dres = None
+        if cfg.bn is not None:
+            sums = torch.zeros(AM_STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=dev)
+            L.am_bn_bwd_reduce(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), int(cfg.relu), ptr(sums), P,
+                               cout, stream())
+            coef = torch.empty(3 * cout, dtype=torch.float32, device=dev)
+            need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            if need_p:
+                dgamma = torch.zeros(cout, dtype=torch.float32, device=dev)
+                dbeta = torch.zeros(cout, dtype=torch.float32, device=dev)
+            L.am_bn_bwd_finalize(ptr(sums), AM_STATS_REPLICAS, float(P), ptr(gamma), ptr(rstd), inv, ptr(dgamma), ptr(dbeta),
+                                 ptr(coef), cout, stream())
+            if not ctx.use_batch:
+                coef[cout:].zero_()  # eval-mode BN: statistics are constants
+            dz = torch.empty_like(dy)
+            dres_t = torch.empty_like(dy) if (ctx.has_res and ctx.needs_input_grad[5]) else None
+            L.am_bn_bwd_apply(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), int(cfg.relu),
+                              ptr(dz), ldo, ptr(dres_t), ldo, P, cout, stream())
+            dres = dres_t
+            if b is not None and ctx.needs_input_grad[2]:
+                # conv bias feeding a train-mode BN has an exactly zero gradient; in eval mode it is colsum(dz)
+                db = torch.zeros_like(b)
+                if not ctx.use_batch:
+                    L.am_bias_relu_bwd(code, ptr(dz), ldo, None, 0, 0, None, 0, ptr(db), inv, P, ldo, cout, stream())
+        else:
+            need_b = b is not None and ctx.needs_input_grad[2]
+            if cfg.relu or need_b:
+                db = torch.zeros_like(b) if need_b else None
+                dz = torch.empty_like(dy) if cfg.relu else dy
+                L.am_bias_relu_bwd(code, ptr(dy), ldo, ptr(y), ldo, int(cfg.relu), ptr(dz) if cfg.relu else None, ldo, ptr(db),
+                                   inv, P, ldo, cout, stream())
+            else:
+                dz = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            _, IH, IW, ldi = x.shape
+            dx = torch.empty_like(x)
+            for idx, (gd, taps) in enumerate(dgrad_plans(s, B, IH, IW, ldi, ldo, es)):
+                wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
+                conv_gemm(gd, dz, wd, None, False, dx, None)
+        if ctx.needs_input_grad[1]:
+            ktot = g.ntaps * g.krun
+            dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
+            conv_wgrad(g, x, dz, inv, dwp)
+            dw = unpack_wgrad(dwp, s, dtype)
+        return dx, dw, db, dgamma, dbeta, dres, None, None
+
+
+def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return ConvBnAct.apply(x, w, b, gamma, beta, residual, cfg, training)

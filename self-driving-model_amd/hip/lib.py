@@ -1,0 +1,101 @@
+"""ctypes binding of libautomoe_hip.so (include/automoe_hip.h).
+
+The prototypes are read from the header itself, so the binding cannot drift from the C ABI: every
+`int am_*(...)` declaration becomes a checked Python callable `lib.am_*`.  There is NO fallback:
+if the shared library is missing or a symbol is absent, import of the product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "automoe_hip.h")
+LIB_PATH = os.path.join(_PKG, "csrc", "libautomoe_hip.so")
+
+AM_F32, AM_F16 = 0, 1
+AM_MAX_TAPS = 16
+AM_STATS_REPLICAS = 16
+AM_MAX_EXPERTS = 8
+
+_ERR = {-1: "AM_ERR_ARG (bad argument)", -2: "AM_ERR_LAUNCH (HIP runtime refused the launch)",
+        -3: "AM_ERR_UNSUPPORTED (shape/dtype not built)"}
+
+
+class ConvGeom(ctypes.Structure):
+    """am_conv_geom of include/automoe_hip.h."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "MH", "MW", "IH", "IW", "ldi", "x_coff", "OH", "OW", "ldo", "y_coff", "oys", "oy0", "oxs", "ox0",
+        "iys", "ixs", "ntaps", "krun", "pix_shift", "N")] + [("dy", ctypes.c_int16 * AM_MAX_TAPS),
+                                                               ("dx", ctypes.c_int16 * AM_MAX_TAPS)]
+
+
+_SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
+            "unsigned long long": ctypes.c_ulonglong, "am_stream_t": ctypes.c_void_p}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, List[Tuple[str, object]]]:
+    """{symbol: [(arg name, ctypes type), ...]} for every `int am_*(...)` prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(am_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        out = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    out.append((a.split("*")[-1].strip() or "p", ctypes.c_void_p))
+                    continue
+                toks = a.replace("const ", "").split()
+                ctype = " ".join(toks[:-1])
+                if ctype not in _SCALARS:
+                    raise RuntimeError(f"{path}: unknown C type '{ctype}' in {name}")
+                out.append((toks[-1], _SCALARS[ctype]))
+        protos[name] = out
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C self-driving-model_amd/csrc`). There is no CPU fallback for the product path.")
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, args in self.protos.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise RuntimeError(f"{LIB_PATH} does not export {name} declared in {HEADER}") from e
+            fn.restype = ctypes.c_int
+            fn.argtypes = [t for _, t in args]
+            setattr(self, "_raw_" + name, fn)
+            if name in ("am_version", "am_conv_npad"):
+                setattr(self, name, fn)
+            else:
+                setattr(self, name, self._checked(name, fn))
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def get() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

@@ -1,0 +1,305 @@
+"""autograd nodes over the C ABI for everything on the path that is not the conv itself:
+layout changes at the NCHW-fp32 boundary, max-pool, global average pools, bilinear upsample,
+pixel-wise cross entropy, and the fp32 MoE-tail ops (linear, LayerNorm, dropout, gate combine).
+
+Every node calls libautomoe_hip.so on PyTorch's current HIP stream; none has a torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib as _lib
+from .conv import dt_code, ptr, require_hip, stream
+
+
+def _L():
+    return _lib.get()
+
+
+# --------------------------------------------------------------------------------------------
+# boundary layout
+# --------------------------------------------------------------------------------------------
+def image_to_nhwc(img: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[B,3,H,W] fp32 NCHW (the reference's batch['image']) -> [B,H,W,16 B/pixel] NHWC `dtype`.  No gradient:
+    the image is never a leaf that requires grad on this path."""
+    require_hip(img, "image")
+    img = img.detach()
+    if img.dtype != torch.float32:
+        img = img.float()
+    img = img.contiguous()
+    B, C, H, W = img.shape
+    ld = 16 // torch.empty((), dtype=dtype).element_size()
+    if C > ld:
+        raise ValueError(f"image has {C} channels; the first-layer kernel handles at most {ld}")
+    out = torch.empty((B, H, W, ld), dtype=dtype, device=img.device)
+    _L().am_nchw_to_nhwc(dt_code(dtype), ptr(img), ptr(out), B, C, H, W, ld, 1.0, stream())
+    return out
+
+
+class NhwcToNchw(torch.autograd.Function):
+    """[B,h,w,ld] NHWC `dtype` -> [B,C,h,w] fp32 NCHW (expert head outputs handed to the trainer).
+    Backward converts the fp32 gradient back and applies the loss scale of the fp16 region."""
+
+    @staticmethod
+    def forward(ctx, x, C: int, loss_scale: float):
+        B, H, W, ld = x.shape
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        _L().am_nhwc_to_nchw(dt_code(x.dtype), ptr(x), ptr(out), B, C, H, W, ld, 1.0, stream())
+        ctx.meta = (x.dtype, ld, loss_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, ld, ls = ctx.meta
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        dx = torch.empty((B, H, W, ld), dtype=dtype, device=g.device)
+        _L().am_nchw_to_nhwc(dt_code(dtype), ptr(g), ptr(dx), B, C, H, W, ld, float(ls), stream())
+        return dx, None, None
+
+
+class MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, IH, IW, C = x.shape
+        OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+        y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+        need = x.requires_grad
+        arg = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device) if need else None
+        _L().am_maxpool3x3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), ptr(arg), B, IH, IW, C, stream())
+        ctx.shape = (B, IH, IW, C)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, IH, IW, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((B, IH, IW, C), dtype=dy.dtype, device=dy.device)
+        _L().am_maxpool3x3s2_bwd(dt_code(dy.dtype), ptr(dy), ptr(arg), ptr(dx), B, IH, IW, C, stream())
+        return dx
+
+
+class GapNhwc(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1)+flatten on NHWC `dtype` -> [B,C] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, loss_scale: float):
+        B, H, W, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _L().am_gap_nhwc_fwd(dt_code(x.dtype), ptr(x), C, ptr(out), B, H * W, C, stream())
+        ctx.meta = (x.dtype, B, H, W, C, loss_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, B, H, W, C, ls = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty((B, H, W, C), dtype=dtype, device=g.device)
+        _L().am_gap_nhwc_bwd(dt_code(dtype), ptr(g), ptr(dx), C, B, H * W, C, float(ls), stream())
+        return dx, None
+
+
+class GapPlane(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1)+flatten on NCHW fp32 -> [B,C] (the extractors' first op)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_hip(x, "extractor input")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _L().am_gap_plane_fwd(ptr(x), ptr(out), B * C, H * W, stream())
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+        _L().am_gap_plane_bwd(ptr(g), ptr(dx), B * C, H * W, stream())
+        return dx
+
+
+class BilinearUp(torch.autograd.Function):
+    """F.interpolate(bilinear, align_corners=False): [B,h,w,ld] NHWC `dtype` -> [B,C,H,W] fp32."""
+
+    @staticmethod
+    def forward(ctx, low, C: int, H: int, W: int, loss_scale: float):
+        B, h, w, ld = low.shape
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=low.device)
+        _L().am_bilinear_up_fwd(dt_code(low.dtype), ptr(low), ld, ptr(out), B, C, h, w, H, W, stream())
+        ctx.meta = (low.dtype, B, C, h, w, ld, H, W, loss_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, B, C, h, w, ld, H, W, ls = ctx.meta
+        g = g.contiguous()
+        dlow = (torch.zeros if ld != C else torch.empty)((B, h, w, ld), dtype=dtype, device=g.device)
+        _L().am_bilinear_up_bwd(dt_code(dtype), ptr(g), ptr(dlow), ld, B, C, h, w, H, W, float(ls), None, stream())
+        return dlow, None, None, None, None
+
+
+class CrossEntropy2d(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index) on [B,C,H,W] fp32 logits / [B,H,W] int64 targets -> scalar (mean over
+    valid pixels).  The valid count never leaves the device."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index: int):
+        require_hip(logits, "logits")
+        logits = logits.contiguous()
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            target = target.long()
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        acc = torch.empty(2, dtype=torch.float64, device=logits.device)
+        _L().am_ce2d_fwd(ptr(logits), ptr(target), B, C, HW, int(ignore_index), ptr(acc), stream())
+        ctx.save_for_backward(logits, target, acc)
+        ctx.meta = (B, C, HW, int(ignore_index))
+        return (acc[0] / acc[1]).float()  # 0/0 -> nan when every pixel is ignored, as torch
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, acc = ctx.saved_tensors
+        B, C, HW, ign = ctx.meta
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _L().am_ce2d_bwd(ptr(logits), ptr(target), B, C, HW, ign, ptr(acc), ptr(g), ptr(d), stream())
+        return d, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# fp32 MoE tail
+# --------------------------------------------------------------------------------------------
+class LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b) for nn.Linear weights; optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu: bool):
+        require_hip(x, "linear input")
+        x = x.contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _L().am_linear_fwd(ptr(x), K, ptr(W), ptr(b), ptr(y), N, M, N, K, int(relu), stream())
+        ctx.relu = relu
+        ctx.save_for_backward(x, W, y if relu else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _L().am_linear_bwd_input(ptr(dy), N, ptr(y), N, ptr(W), ptr(dx), K, M, N, K, 0, stream())
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dW = torch.zeros_like(W)
+            db = torch.zeros(N, dtype=torch.float32, device=W.device) if ctx.has_b else None
+            _L().am_linear_bwd_weight(ptr(dy), N, ptr(y), N, ptr(x), K, ptr(dW), ptr(db), M, N, K, stream())
+        return dx, dW, db, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        require_hip(x, "layernorm input")
+        x = x.contiguous()
+        M, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _L().am_layernorm_fwd(ptr(x), D, ptr(gamma), ptr(beta), float(eps), ptr(y), D, ptr(mean), ptr(rstd), M, D, stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, D = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = torch.zeros_like(gamma) if need_p else None
+        db = torch.zeros_like(gamma) if need_p else None
+        _L().am_layernorm_bwd(ptr(dy), D, ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), D, ptr(dg), ptr(db), M, D, stream())
+        return dx, dg, db, None
+
+
+_DROPOUT_CALLS = 0
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in train mode.  Counter-based RNG seeded from torch's generator seed plus a call
+    counter: same distribution as torch's, not the same stream."""
+
+    @staticmethod
+    def forward(ctx, x, p: float):
+        global _DROPOUT_CALLS
+        require_hip(x, "dropout input")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _DROPOUT_CALLS += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + _DROPOUT_CALLS * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        _L().am_dropout_fwd(ptr(x), ptr(y), ptr(mask), x.numel(), float(p), seed, stream())
+        ctx.p = p
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _L().am_dropout_bwd(ptr(dy), ptr(mask), ptr(dx), dy.numel(), float(ctx.p), stream())
+        return dx, None
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    return arr
+
+
+class GateCombine(torch.autograd.Function):
+    """(weights, combined) = gate(logits, processed...) -- gating_network.py:149-166.  `logits` are the
+    (already noised, if any) gate logits; top-k masking, temperature softmax or sigmoid-normalise and the
+    softmax-weighted expert combine run in one kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, temperature: float, use_softmax: bool, top_k: int, *processed):
+        require_hip(logits, "gate logits")
+        logits = logits.contiguous()
+        processed = [p.contiguous() for p in processed]
+        B, E = logits.shape
+        D = processed[0].shape[1]
+        weights = torch.empty((B, E), dtype=torch.float32, device=logits.device)
+        combined = torch.empty((B, D), dtype=torch.float32, device=logits.device)
+        _L().am_gate_combine_fwd(ptr(logits), _ptr_array(processed), E, D, float(temperature), int(use_softmax), int(top_k),
+                                 ptr(weights), ptr(combined), B, D, stream())
+        ctx.meta = (float(temperature), int(use_softmax), int(top_k), B, E, D)
+        ctx.save_for_backward(logits, *processed)
+        return weights, combined
+
+    @staticmethod
+    def backward(ctx, dweights, dcombined):
+        logits, *processed = ctx.saved_tensors
+        temperature, use_softmax, top_k, B, E, D = ctx.meta
+        dcombined = (dcombined if dcombined is not None else torch.zeros((B, D), device=logits.device)).contiguous()
+        dweights = dweights.contiguous() if dweights is not None else None
+        dlogits = torch.empty_like(logits)
+        dproc = [torch.empty_like(p) for p in processed]
+        _L().am_gate_combine_bwd(ptr(logits), _ptr_array(processed), E, D, temperature, use_softmax, top_k, ptr(dcombined),
+                                 ptr(dweights), ptr(dlogits), _ptr_array(dproc), B, D, stream())
+        return (dlogits, None, None, None, *dproc)

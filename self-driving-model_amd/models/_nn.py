@@ -1,0 +1,97 @@
+"""Parameter containers with HIP forwards.  They subclass the torch.nn layer types so constructor
+signatures, default initialisation and state_dict keys are the reference's (checkpoints load
+strict=True either way), but every forward runs libautomoe_hip.so kernels; none calls torch.nn.functional.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import runtime
+from ..hip import conv as hconv
+from ..hip import ops as hops
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters + the gather-GEMM description.  Used through conv_bn_act(), not called directly."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__(cin, cout, kernel_size, stride, padding, bias=bias)
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.spec = hconv.ConvSpec(cin, cout, k, stride, padding, first=(cin == 3))
+        self._packed = hconv.PackedWeights()
+
+    def forward(self, x):  # pragma: no cover - guarded
+        raise RuntimeError("Conv2d is driven through conv_bn_act() on NHWC activations")
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x):  # pragma: no cover - guarded
+        raise RuntimeError("BatchNorm2d is fused into conv_bn_act()")
+
+
+def conv_bn_act(x: torch.Tensor, conv: Conv2d, bn: Optional[BatchNorm2d], relu: bool,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(BN(conv(x)) + residual) on NHWC activations; BN mode follows bn.training."""
+    cfg = hconv._Cfg(conv.spec, conv._packed, bn, relu, runtime.loss_scale())
+    training = bn.training if bn is not None else False
+    return hconv.conv_bn_act(x, conv.weight, conv.bias, bn, relu, residual, cfg, training)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, relu: bool = False):
+        return hops.LinearAct.apply(x, self.weight, self.bias, relu)
+
+
+class ReLU(nn.ReLU):
+    """Placeholder kept for state_dict index parity; MLPSequential fuses it into the preceding Linear."""
+
+    def forward(self, x):  # pragma: no cover - guarded
+        raise RuntimeError("ReLU must follow a Linear inside an MLPSequential (it is fused into it)")
+
+
+class Dropout(nn.Dropout):
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return hops.DropoutFn.apply(x, self.p)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return hops.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class GlobalAvgPoolNCHW(nn.AdaptiveAvgPool2d):
+    """nn.AdaptiveAvgPool2d((1,1)) + nn.Flatten on an NCHW fp32 tensor -> [B,C]."""
+
+    def __init__(self):
+        super().__init__((1, 1))
+
+    def forward(self, x):
+        return hops.GapPlane.apply(x)
+
+
+class Flatten(nn.Flatten):
+    def forward(self, x):
+        return x if x.dim() == 2 else x.flatten(1)
+
+
+class MLPSequential(nn.Sequential):
+    """nn.Sequential whose Linear -> ReLU pairs run as one fused kernel."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Linear):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = m(x, relu=fuse)
+                i += 2 if fuse else 1
+            else:
+                x = m(x)
+                i += 1
+        return x

@@ -1,0 +1,164 @@
+"""AutoMoE composition -- drop-in for models/automoe.py:13-298 (API surface: create_automoe_model,
+AutoMoE.forward(batch) -> 8-key dict, load_expert_checkpoints, freeze_experts / unfreeze_experts,
+get_expert_weights).
+
+MI355X-first differences in HOW (results are the reference's):
+  * the image is converted once to NHWC (16 B per pixel) and shared by the three expert trunks and
+    the policy backbone, instead of four independent NCHW reads;
+  * an expert failure is not silently replaced by zeros unless AUTOMOE_SWALLOW_EXPERT_ERRORS=1
+    (the reference's try/except at automoe.py:181-185 hides shape bugs): it warns and re-raises.
+"""
+import os
+import warnings
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from .. import runtime
+from ..hip import ops as hops
+from .context.context_features import create_context_extractor
+from .experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
+from .experts.expert_extractors import create_expert_extractors
+from .gating.gating_network import GatingNetwork
+from .policy.trajectory_head import TrajectoryPolicy
+
+
+def _last_step(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() == 2 and t.size(1) > 1:
+        return t[:, -1:].contiguous()
+    if t.dim() > 2:
+        return t.view(t.size(0), -1)[:, -1:].contiguous()
+    return t
+
+
+class AutoMoE(nn.Module):
+    """Complete AutoMoE: Mixture of Experts Self-Driving Model"""
+
+    def __init__(self, expert_configs: List[Dict], gating_config: Dict, context_config: Dict, policy_config: Dict,
+                 device: str = "cuda"):
+        super().__init__()
+        self.device = device
+        self.expert_configs = expert_configs
+        self.gating_config = gating_config
+        self.context_config = context_config
+        self.policy_config = policy_config
+        self.experts = self._create_experts()
+        self.expert_extractors = create_expert_extractors(expert_configs)
+        self.context_extractor = create_context_extractor(context_config)
+        self.gating_network = self._create_gating_network()
+        self.policy_head = self._create_policy_head()
+        self.to(device)
+
+    def _create_experts(self) -> nn.ModuleList:
+        experts = nn.ModuleList()
+        for config in self.expert_configs:
+            t = config["type"]
+            if t == "detection":
+                e = BDDDetectionExpert(num_classes=config.get("num_classes", 10),
+                                       pretrained_backbone=config.get("pretrained_backbone", True))
+            elif t == "segmentation":
+                e = BDDSegmentationExpert(num_classes=config.get("num_classes", 19),
+                                          pretrained_backbone=config.get("pretrained_backbone", True))
+            elif t == "drivable":
+                e = BDDDrivableExpert(num_classes=config.get("num_classes", 3),
+                                      pretrained_backbone=config.get("pretrained_backbone", True))
+            elif t == "nuscenes":
+                raise ValueError("Unknown expert type: nuscenes (NuScenesExpert hard-codes a pretrained fetch in the "
+                                 "reference and is outside this build's hot-path scope; see DESIGN.md)")
+            else:
+                raise ValueError(f"Unknown expert type: {t}")
+            experts.append(e)
+        return experts
+
+    def _create_gating_network(self) -> GatingNetwork:
+        return GatingNetwork(
+            num_experts=len(self.expert_configs),
+            context_dim=self.context_config.get("context_dim", 64),
+            expert_output_dims=[c.get("output_dim", 256) for c in self.expert_configs],
+            processed_dim=self.gating_config.get("processed_dim", 256),
+            hidden_dim=self.gating_config.get("hidden_dim", 128),
+            temperature=self.gating_config.get("temperature", 1.0),
+            use_softmax=self.gating_config.get("use_softmax", True))  # top_k / noise keys are ignored, as in the reference
+
+    def _create_policy_head(self) -> TrajectoryPolicy:
+        return TrajectoryPolicy(horizon=self.policy_config.get("num_waypoints", 10),
+                                context_dim=self.gating_config.get("processed_dim", 256),
+                                backbone_dim=self.policy_config.get("backbone_dim", 512))
+
+    def _extract_context_features(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        if self.context_config.get("type", "simple") != "simple":
+            raise ValueError("only the 'simple' context extractor is on the accelerated path")
+        speed = batch["speed"]
+        speed_in = speed[:, -1:].contiguous() if speed.dim() == 2 and speed.size(1) > 1 else speed
+        if all(k in batch for k in ("speed", "steering", "throttle", "brake")):
+            steering, throttle, brake = (_last_step(batch[k]) for k in ("steering", "throttle", "brake"))
+        else:
+            bsz, device = speed_in.size(0), speed_in.device
+            steering = torch.zeros(bsz, 1, device=device)
+            throttle = torch.zeros(bsz, 1, device=device)
+            brake = torch.zeros(bsz, 1, device=device)
+        return self.context_extractor(speed_in, steering, throttle, brake)
+
+    def _run_experts(self, batch: Dict[str, torch.Tensor], nhwc: torch.Tensor) -> List:
+        outs = []
+        for i, expert in enumerate(self.experts):
+            try:
+                outs.append(expert(batch["image"], nhwc_input=nhwc))
+            except Exception as e:  # noqa: BLE001
+                warnings.warn(f"Error running expert {i} ({self.expert_configs[i]['type']}): {e}")
+                if os.environ.get("AUTOMOE_SWALLOW_EXPERT_ERRORS", "0") != "1":
+                    raise
+                outs.append(torch.zeros(batch["image"].size(0), self.expert_configs[i].get("output_dim", 256),
+                                        device=batch["image"].device))
+        return outs
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        context_features = self._extract_context_features(batch)
+        nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
+        expert_outputs = self._run_experts(batch, nhwc)
+        expert_features = self.expert_extractors.extract_features(expert_outputs)
+        gating_output = self.gating_network(expert_features, context_features)
+        policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc)
+        speed_seq = policy_output.get("speed")
+        speed_out = speed_seq[:, -1:].contiguous() if speed_seq is not None and speed_seq.dim() == 2 else None
+        return {
+            "waypoints": policy_output["waypoints"],
+            "speed": speed_out if speed_out is not None else speed_seq,
+            "speed_seq": speed_seq,
+            "expert_weights": gating_output["expert_weights"],
+            "expert_outputs": expert_outputs,
+            "context_features": context_features,
+            "combined_features": gating_output["combined_output"],
+            "gate_logits": gating_output["gate_logits"],
+        }
+
+    def get_expert_weights(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        return self.gating_network.get_expert_weights(self._extract_context_features(batch))
+
+    def load_expert_checkpoints(self, checkpoint_paths: List[str]):
+        if len(checkpoint_paths) != len(self.experts):
+            raise ValueError(f"Expected {len(self.experts)} checkpoint paths, got {len(checkpoint_paths)}")
+        for i, (expert, path) in enumerate(zip(self.experts, checkpoint_paths)):
+            if path and path != "":
+                try:
+                    checkpoint = torch.load(path, map_location=self.device, weights_only=True)
+                    expert.load_state_dict(checkpoint.get("model_state_dict", checkpoint))
+                    print(f"Loaded checkpoint for expert {i}: {path}")
+                except Exception as e:  # noqa: BLE001
+                    warnings.warn(f"Failed to load checkpoint for expert {i}: {e}")
+
+    def freeze_experts(self):
+        for expert in self.experts:
+            for p in expert.parameters():
+                p.requires_grad = False
+
+    def unfreeze_experts(self):
+        for expert in self.experts:
+            for p in expert.parameters():
+                p.requires_grad = True
+
+
+def create_automoe_model(config: Dict, device: str = "cuda") -> AutoMoE:
+    return AutoMoE(expert_configs=config["experts"], gating_config=config["gating"], context_config=config["context"],
+                   policy_config=config["policy"], device=device)

@@ -1,0 +1,90 @@
+"""ResNet-18 trunk (torchvision `resnet18`, children()[:-2]) as the reference uses it at
+models/experts/bdd_detection_expert.py:9-10, bdd_segmentation_expert.py:10-11, bdd_drivable_expert.py:10-11.
+
+Same child order and names as torchvision, so the state_dict keys are `backbone.0.weight`,
+`backbone.1.running_mean`, `backbone.4.0.conv1.weight`, `backbone.5.0.downsample.0.weight`, ...
+Compute: NHWC gather-GEMM convs with BatchNorm batch statistics in the conv epilogue and
+normalise + residual + ReLU in one elementwise pass (hip/conv.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ...hip import ops as hops
+from .._nn import BatchNorm2d, Conv2d, conv_bn_act
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(Conv2d(cin, cout, 1, stride, 0, bias=False), BatchNorm2d(cout))
+        self.stride = stride
+
+    def forward(self, x):  # x: NHWC
+        idn = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        y = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        return conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idn)
+
+
+class MaxPool(nn.MaxPool2d):
+    def __init__(self):
+        super().__init__(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        return hops.MaxPool3x3s2.apply(x)
+
+
+class Trunk(nn.Sequential):
+    """Sequential(conv1, bn1, relu, maxpool, layer1, layer2, layer3, layer4); forward takes and returns NHWC."""
+
+    def __init__(self):
+        def stage(cin, cout, stride):
+            return nn.Sequential(BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1))
+
+        super().__init__(Conv2d(3, 64, 7, 2, 3, bias=False), BatchNorm2d(64), nn.ReLU(inplace=True), MaxPool(),
+                         stage(64, 64, 1), stage(64, 128, 2), stage(128, 256, 2), stage(256, 512, 2))
+        for m in self.modules():  # torchvision ResNet.__init__
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+
+    def forward(self, x):
+        x = conv_bn_act(x, self[0], self[1], relu=True)
+        x = self[3](x)
+        for i in range(4, 8):
+            for blk in self[i]:
+                x = blk(x)
+        return x
+
+
+def load_pretrained_(trunk: Trunk, flag: bool):
+    """pretrained_backbone=True means torchvision's ImageNet weights: a network fetch in the reference.
+    Offline it needs a local state_dict: set AUTOMOE_RESNET18_WEIGHTS to a torchvision resnet18 .pth file."""
+    if not flag:
+        return
+    import os
+    path = os.environ.get("AUTOMOE_RESNET18_WEIGHTS", "")
+    if not path or not os.path.exists(path):
+        raise RuntimeError("pretrained_backbone=True needs torchvision's ImageNet ResNet-18 weights, which the reference "
+                           "downloads; there is no network here. Point AUTOMOE_RESNET18_WEIGHTS at a local resnet18 "
+                           "state_dict (.pth) or pass pretrained_backbone=False.")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    names = ["conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"]
+    remap = {}
+    for k, v in sd.items():
+        head = k.split(".")[0]
+        if head in names:
+            remap[str(names.index(head)) + k[len(head):]] = v
+    trunk.load_state_dict(remap, strict=True)

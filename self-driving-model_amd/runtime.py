@@ -1,0 +1,56 @@
+"""Process-wide numeric configuration of the HIP path.
+
+compute dtype: torch.float16 (default; MFMA f16 with fp32 accumulation, fp32 master weights) or
+torch.float32 (exact-fp32 MFMA; the parity mode that is compared with the reference's CPU fp32
+arithmetic at rtol 1e-3 / atol 1e-5).
+loss scale: gradients that flow through fp16 activations are multiplied by this constant where they
+enter the fp16 region and divided out where they leave it (weight / BN / bias gradients), so the
+fp32 parameter gradients are unscaled.  1.0 in fp32 mode.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+_STATE = {"dtype": torch.float16, "loss_scale": 16384.0, "weight_epoch": 0}
+
+
+def compute_dtype() -> torch.dtype:
+    return _STATE["dtype"]
+
+
+def set_compute_dtype(dtype: torch.dtype, loss_scale: float | None = None):
+    if dtype not in (torch.float16, torch.float32):
+        raise ValueError("compute dtype must be torch.float16 or torch.float32")
+    _STATE["dtype"] = dtype
+    if loss_scale is not None:
+        _STATE["loss_scale"] = float(loss_scale)
+
+
+def loss_scale() -> float:
+    return _STATE["loss_scale"] if _STATE["dtype"] == torch.float16 else 1.0
+
+
+def set_loss_scale(v: float):
+    _STATE["loss_scale"] = float(v)
+
+
+def weight_epoch() -> int:
+    """Bumped by the fused optimizer after every in-place parameter update made through raw pointers
+    (which torch's tensor version counter does not see); packed-weight caches key on it."""
+    return _STATE["weight_epoch"]
+
+
+def bump_weight_epoch():
+    _STATE["weight_epoch"] += 1
+
+
+@contextlib.contextmanager
+def precision(dtype: torch.dtype, loss_scale: float | None = None):
+    old = dict(_STATE)
+    set_compute_dtype(dtype, loss_scale)
+    try:
+        yield
+    finally:
+        _STATE.update({"dtype": old["dtype"], "loss_scale": old["loss_scale"]})

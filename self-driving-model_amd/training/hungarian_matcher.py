@@ -1,0 +1,60 @@
+"""HungarianMatcher -- drop-in for training/hungarian_matcher.py:13-85 (2-D boxes, D == 4).
+
+The reference computes one cost matrix per image on the GPU, copies it to the host and calls
+scipy.optimize.linear_sum_assignment (B device->host syncs per step).  Here the batched cost kernel and
+the batched LSAP kernel both run on the MI355X; the only host interaction of `forward` is one read of
+the per-image status words so NaN costs raise ValueError exactly as scipy does.  `match_padded` is the
+sync-free entry the fused detection loss uses.
+"""
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..hip import matcher as hm
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class=1.0, cost_bbox=5.0, cost_giou=2.0):
+        super().__init__()
+        self.cost_class = cost_class
+        self.cost_bbox = cost_bbox
+        self.cost_giou = cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0
+
+    @torch.no_grad()
+    def match_padded(self, pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt):
+        """Padded targets ([B,Nmax] labels, [B,Nmax,4] cxcywh boxes, [B] counts) -> device tensors
+        (pred_idx [B,k], tgt_idx [B,k], count [B], status [B]); no host synchronisation."""
+        if pred_boxes.shape[-1] != 4:
+            raise NotImplementedError("only 4-dim (cx,cy,w,h) boxes are on the accelerated path")
+        cost = hm.match_cost(pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt, self.cost_class, self.cost_bbox,
+                             self.cost_giou)
+        return hm.lsap_batched(cost, n_tgt, transposed_storage=True)
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        pred_logits, pred_boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        B, Q, _ = pred_logits.shape
+        dev = pred_logits.device
+        counts = [int(t["labels"].shape[0]) for t in targets]
+        nmax = max(counts) if counts else 0
+        labels = torch.full((B, max(nmax, 1)), -1, dtype=torch.int64, device=dev)
+        boxes = torch.zeros((B, max(nmax, 1), 4), dtype=torch.float32, device=dev)
+        for b, t in enumerate(targets):
+            if counts[b]:
+                labels[b, : counts[b]] = t["labels"].to(dev)
+                boxes[b, : counts[b]] = t["boxes"].to(dev).float()
+        n_tgt = torch.tensor(counts, dtype=torch.int32, device=dev)
+        rows, cols, count, status = self.match_padded(pred_logits, pred_boxes, labels, boxes, n_tgt)
+        st = status.tolist()  # the one host read: scipy's ValueError semantics
+        for b, s in enumerate(st):
+            if s == -2:
+                raise ValueError("matrix contains invalid numeric entries")
+            if s == -1:
+                raise ValueError("cost matrix is infeasible")
+        out = []
+        for b in range(B):
+            k = min(Q, counts[b])
+            out.append((rows[b, :k].clone(), cols[b, :k].clone()))
+        return out

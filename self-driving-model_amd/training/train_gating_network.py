@@ -1,0 +1,193 @@
+"""AutoMoE gating-stage trainer -- drop-in for training/train_gating_network.py (compute_gating_losses :21-74,
+train_one_epoch :76-117, validate :119-158, save/load_checkpoint :160-191, main :193-343).
+
+Differences in HOW: the step glue is FusedAdamW (clip 1.0 folded in, norm on device) + GradBucketReducer
+(RCCL all-reduce overlapped with backward) instead of torch DDP + clip_grad_norm_ + AdamW, there is no
+per-step .item() sync (losses are accumulated on the device and read once per epoch), and `--synthetic`
+replaces the CARLA dataset (absent offline) with batches of the same dict layout.
+"""
+import argparse
+import json
+import os
+from typing import Dict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401  (kept for API parity with the reference module namespace)
+
+from ..models.automoe import create_automoe_model
+from . import synthetic
+from .ddp import DataParallel, GradBucketReducer
+from .optim import FusedAdamW
+
+
+def _l1(a, b):
+    return (a - b).abs().mean()
+
+
+def compute_gating_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor, target_spd: torch.Tensor,
+                          config: Dict) -> Dict[str, torch.Tensor]:
+    """ADE / FDE / speed L1 + smoothness + load-balance MSE + negative entropy; weights 1, 2, .2, .1, .01, .001."""
+    wp = pred["waypoints"]
+    ade = _l1(wp, target_wp)
+    fde = _l1(wp[:, -1, :], target_wp[:, -1, :])
+    pred_spd = pred.get("speed_seq", pred.get("speed"))
+    if pred_spd is not None and pred_spd.dim() == 2 and target_spd.dim() == 2 and pred_spd.size(1) == target_spd.size(1):
+        speed_loss = _l1(pred_spd, target_spd)
+    else:
+        pred_last = pred.get("speed")
+        if pred_last is not None and pred_last.dim() == 2 and pred_last.size(1) == 1:
+            speed_loss = _l1(pred_last, target_spd[:, -1:].contiguous())
+        else:
+            speed_loss = torch.zeros((), device=target_spd.device)
+    d = wp[:, 1:, :] - wp[:, :-1, :]
+    smoothness_loss = _l1(d[:, 1:, :], d[:, :-1, :])
+    w = pred["expert_weights"]
+    if config.get("use_load_balancing", True):
+        usage = w.mean(dim=0)
+        load_balancing_loss = ((usage - 1.0 / usage.size(0)) ** 2).mean()
+    else:
+        load_balancing_loss = torch.tensor(0.0, device=w.device)
+    if config.get("use_entropy_loss", True):
+        entropy_loss = (w * torch.log(w + 1e-8)).sum(dim=1).mean()  # = -entropy
+    else:
+        entropy_loss = torch.tensor(0.0, device=w.device)
+    total = (config.get("ade_weight", 1.0) * ade + config.get("fde_weight", 2.0) * fde
+             + config.get("speed_weight", 0.2) * speed_loss + config.get("smoothness_weight", 0.1) * smoothness_loss
+             + config.get("load_balancing_weight", 0.01) * load_balancing_loss
+             + config.get("entropy_weight", 0.001) * entropy_loss)
+    return {"total_loss": total, "ade": ade, "fde": fde, "speed": speed_loss, "smoothness": smoothness_loss,
+            "load_balancing": load_balancing_loss, "entropy": entropy_loss}
+
+
+class GatingTrainStep:
+    """One optimisation step of the gating stage: zero_grad -> forward -> losses -> backward (+ overlapped
+    all-reduce) -> clip 1.0 + AdamW.  Holds the optimizer / reducer pair so callers (trainer, bench) share it."""
+
+    def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = 25):
+        self.model = model
+        self.core = model.module if hasattr(model, "module") else model
+        self.config = config
+        params = [p for p in self.core.parameters() if p.requires_grad]
+        self.optimizer = FusedAdamW(params, lr=config.get("learning_rate", 1e-4), weight_decay=config.get("weight_decay", 1e-4),
+                                    max_norm=1.0)
+        self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
+                                         bucket_bytes=bucket_mb << 20, broadcast_from=self.optimizer.flat_p)
+        self.optimizer.grad_divisor = float(self.reducer.world)
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        self.optimizer.zero_grad()
+        pred = self.model(batch)
+        losses = compute_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
+        losses["total_loss"].backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        return losses
+
+
+def train_one_epoch(model, loader, optimizer, device, epoch_idx, epochs, rank, config, step: GatingTrainStep = None) -> float:
+    model.train()
+    step = step or GatingTrainStep(model, config)
+    total = torch.zeros((), device=device)
+    n = 0
+    for batch in loader:
+        batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        losses = step(batch)
+        total += losses["total_loss"].detach()
+        n += 1
+    return float(total.item()) / max(1, n)
+
+
+@torch.no_grad()
+def validate(model, loader, device, epoch_idx, epochs, rank, world_size, config) -> float:
+    model.eval()
+    total = torch.zeros((), device=device)
+    n = 0
+    for batch in loader:
+        batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        pred = model(batch)
+        total += compute_gating_losses(pred, batch["waypoints"], batch["speed"], config)["total_loss"]
+        n += 1
+    t = torch.stack([total, torch.tensor(float(n), device=device)])
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0].item()) / max(1, int(t[1].item()))
+
+
+def save_checkpoint(model, optimizer, epoch, loss, save_path, rank):
+    if rank == 0:
+        torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                    "loss": loss}, save_path)
+        print(f"Saved checkpoint to {save_path}")
+
+
+def load_checkpoint(model, optimizer, checkpoint_path, device) -> int:
+    if os.path.exists(checkpoint_path):
+        ck = torch.load(checkpoint_path, map_location=device, weights_only=True)
+        model.load_state_dict(ck["model_state_dict"])
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+        print(f"Loaded checkpoint from {checkpoint_path}, starting from epoch {ck['epoch'] + 1}")
+        return ck["epoch"] + 1
+    print(f"No checkpoint found at {checkpoint_path}, starting from epoch 0")
+    return 0
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Train AutoMoE gating network (MI355X HIP path)")
+    parser.add_argument("--config", type=str, required=True)
+    parser.add_argument("--model_config", type=str, default=os.path.join(os.path.dirname(__file__), "..", "models", "configs", "automoe", "model_config.json"))
+    parser.add_argument("--data_root", type=str, default="")
+    parser.add_argument("--checkpoint_dir", type=str, default="models/checkpoints/gating")
+    parser.add_argument("--resume", type=str, default="")
+    parser.add_argument("--expert_checkpoints", nargs="+", default=[])
+    parser.add_argument("--local_rank", type=int, default=0)
+    parser.add_argument("--world_size", type=int, default=1)
+    parser.add_argument("--synthetic", action="store_true", help="synthetic CARLA-shaped batches (no dataset offline)")
+    parser.add_argument("--synthetic_steps", type=int, default=20)
+    parser.add_argument("--precision", choices=["fp16", "fp32"], default="fp16")
+    args = parser.parse_args(argv)
+    from .. import runtime
+    runtime.set_compute_dtype(torch.float16 if args.precision == "fp16" else torch.float32)
+    with open(args.config) as f:
+        config = json.load(f)
+    with open(args.model_config) as f:
+        model_config = json.load(f)
+    world = int(os.environ.get("WORLD_SIZE", str(args.world_size)))
+    if world > 1:
+        args.local_rank = int(os.environ.get("LOCAL_RANK", str(args.local_rank)))
+        args.world_size = world
+        dist.init_process_group(backend="nccl", init_method="env://")  # "nccl" is RCCL on ROCm
+        torch.cuda.set_device(args.local_rank)
+    device = torch.device(f"cuda:{args.local_rank}")
+    model = create_automoe_model(model_config, device)
+    if args.expert_checkpoints:
+        model.load_expert_checkpoints(args.expert_checkpoints)
+    model.freeze_experts()
+    wrapped = DataParallel(model) if world > 1 else model
+    if not args.synthetic:
+        raise SystemExit("the CARLA dataset is not available offline; run with --synthetic")
+    H, W = config.get("image_size", [720, 1280])
+    rank = int(os.environ.get("RANK", "0"))
+    batch = synthetic.carla_sequence_batch(config.get("batch_size", 8), H, W, config.get("sequence_length", 10), device, seed=rank)
+    loader = synthetic.SyntheticLoader(batch, args.synthetic_steps)
+    step = GatingTrainStep(wrapped, config)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(step.optimizer, T_max=config.get("epochs", 100) * len(loader))
+    start = load_checkpoint(wrapped, step.optimizer, args.resume, device) if args.resume else 0
+    os.makedirs(args.checkpoint_dir, exist_ok=True)
+    best = float("inf")
+    for epoch in range(start, config.get("epochs", 100)):
+        tr = train_one_epoch(wrapped, loader, step.optimizer, device, epoch, config.get("epochs", 100), args.local_rank, config, step)
+        va = validate(wrapped, loader, device, epoch, config.get("epochs", 100), args.local_rank, world, config)
+        sched.step()  # once per epoch, as the reference (:314)
+        if rank == 0:
+            print(f"Epoch {epoch + 1}: Train Loss: {tr:.4f}, Val Loss: {va:.4f}, skipped steps: {int(step.optimizer.skipped)}")
+        if va < best:
+            best = va
+            save_checkpoint(wrapped, step.optimizer, epoch, va, os.path.join(args.checkpoint_dir, "best.pth"), rank)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

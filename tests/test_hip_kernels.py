@@ -1,0 +1,374 @@
+"""GPU parity tests, kernel level: every HIP entry point against the torch-CPU fp32 arithmetic the
+reference runs (torch.nn.functional on CPU = the oracle for single ops), through the C ABI.
+
+Tolerance: fp32 mode rtol 1e-3 / atol 1e-5 (BASELINE.json north_star); fp16 mode (MFMA f16, fp32
+accumulate) is checked at a tolerance scaled to fp16's 2^-11 rounding.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-3, 1e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=RT, atol=AT, what=""):
+    a = a.detach().float().cpu().numpy().astype(np.float64)
+    b = b.detach().float().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu().double()
+    b = b.detach().float().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x, dtype, ld=None):
+    """[B,C,H,W] cpu fp32 -> device NHWC with optional channel padding."""
+    B, C, H, W = x.shape
+    ld = ld or C
+    out = torch.zeros(B, H, W, ld, dtype=dtype)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
+    return out.to(_dev())
+
+
+def nchw(y, C):
+    return y[..., :C].permute(0, 3, 1, 2).float().cpu()
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H, W
+    (64, 64, 3, 1, 1, 13, 20),
+    (64, 128, 3, 2, 1, 23, 40),
+    (64, 128, 1, 2, 0, 23, 40),
+    (128, 256, 3, 2, 1, 12, 20),
+    (256, 512, 3, 1, 1, 5, 7),
+    (3, 64, 7, 2, 3, 45, 64),
+    (3, 32, 5, 2, 2, 31, 50),
+    (256, 14, 1, 1, 0, 6, 9),
+    (32, 64, 3, 2, 1, 22, 33),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd_vs_torch(case, dtype):
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    cin, cout, k, st, pad, H, W = case
+    B = 3
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(cin != 3), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.relu(F.conv2d(xr, wr, br, stride=st, padding=pad))
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe).sum().backward()
+
+    spec = hc.ConvSpec(cin, cout, k, st, pad, first=(cin == 3))
+    with runtime.precision(dtype, 1.0):
+        if cin == 3:
+            xd = hops.image_to_nhwc(x.to(_dev()), dtype)
+        else:
+            xd = nhwc(x, dtype).requires_grad_()
+        wd, bd = w.to(_dev()).requires_grad_(), b.to(_dev()).requires_grad_()
+        cfg = hc._Cfg(spec, hc.PackedWeights(), None, True, 1.0)
+        y = hc.conv_bn_act(xd, wd, bd, None, True, None, cfg, False)
+        es = 2 if dtype == torch.float16 else 4
+        ld = hc.channel_ld(cout, es)
+        assert y.shape == (B, yr.shape[2], yr.shape[3], ld)
+        (y[..., :cout].float() * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+    tol = dict(rtol=RT, atol=AT) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    close(nchw(y, cout), yr, what="conv fwd", **tol)
+    if dtype == torch.float32:
+        close(wd.grad, wr.grad, rtol=RT, atol=1e-4, what="wgrad")
+        close(bd.grad, br.grad, rtol=RT, atol=1e-4, what="bias grad")
+        if cin != 3:
+            close(nchw(xd.grad, cin), xr.grad, what="dgrad")
+    else:
+        assert rel_err(wd.grad, wr.grad) < 5e-3
+        assert rel_err(bd.grad, br.grad) < 5e-3
+        if cin != 3:
+            assert rel_err(nchw(xd.grad, cin), xr.grad) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("with_res,conv_bias", [(False, False), (True, False), (False, True)])
+def test_conv_bn_relu_train_vs_torch(dtype, with_res, conv_bias):
+    """conv -> BatchNorm2d(train) -> (+residual) -> ReLU, forward, running stats, all gradients."""
+    import torch.nn as nn
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    B, cin, cout, H, W = 4, 64, 128, 9, 14
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    cb = torch.randn(cout, generator=g) * 0.5 if conv_bias else None
+    res = torch.randn(B, cout, H, W, generator=g) if with_res else None
+    bn_ref = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * torch.randn(cout, generator=g))
+        bn_ref.bias.copy_(0.2 * torch.randn(cout, generator=g))
+        bn_ref.running_mean.copy_(0.1 * torch.randn(cout, generator=g))
+        bn_ref.running_var.copy_(0.5 + torch.rand(cout, generator=g))
+    bn_hip = nn.BatchNorm2d(cout)
+    bn_hip.load_state_dict(bn_ref.state_dict())
+    bn_hip.to(_dev())
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    cbr = cb.clone().requires_grad_() if conv_bias else None
+    rr = res.clone().requires_grad_() if with_res else None
+    z = bn_ref(F.conv2d(xr, wr, cbr, padding=1))
+    yr = F.relu(z + rr if with_res else z)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe).sum().backward()
+    with runtime.precision(dtype, 1.0):
+        xd = nhwc(x, dtype).requires_grad_()
+        wd = w.to(_dev()).requires_grad_()
+        cbd = cb.to(_dev()).requires_grad_() if conv_bias else None
+        rd = nhwc(res, dtype).requires_grad_() if with_res else None
+        cfg = hc._Cfg(hc.ConvSpec(cin, cout, 3, 1, 1), hc.PackedWeights(), bn_hip, True, 1.0)
+        y = hc.ConvBnAct.apply(xd, wd, cbd, bn_hip.weight, bn_hip.bias, rd, cfg, True)
+        (y.float() * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+    if dtype == torch.float32:
+        close(nchw(y, cout), yr, what="y")
+        close(bn_hip.running_mean, bn_ref.running_mean, what="running_mean")
+        close(bn_hip.running_var, bn_ref.running_var, what="running_var")
+        assert int(bn_hip.num_batches_tracked) == 1
+        close(nchw(xd.grad, cin), xr.grad, rtol=RT, atol=1e-4, what="dx")
+        close(wd.grad, wr.grad, rtol=RT, atol=2e-4, what="dw")
+        close(bn_hip.weight.grad, bn_ref.weight.grad, rtol=RT, atol=2e-4, what="dgamma")
+        close(bn_hip.bias.grad, bn_ref.bias.grad, rtol=RT, atol=2e-4, what="dbeta")
+        if with_res:
+            close(nchw(rd.grad, cout), rr.grad, what="dres")
+        if conv_bias:
+            close(cbd.grad, cbr.grad, rtol=RT, atol=2e-4, what="conv bias grad (exactly 0 under train-mode BN)")
+    else:
+        assert rel_err(nchw(y, cout), yr) < 3e-3
+        assert rel_err(bn_hip.running_var, bn_ref.running_var) < 1e-3
+        assert rel_err(nchw(xd.grad, cin), xr.grad) < 1e-2
+        assert rel_err(wd.grad, wr.grad) < 1e-2
+        assert rel_err(bn_hip.weight.grad, bn_ref.weight.grad) < 1e-2
+
+
+def test_bn_eval_mode_vs_torch():
+    import torch.nn as nn
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    B, cin, cout, H, W = 2, 64, 64, 7, 9
+    g = torch.Generator().manual_seed(6)
+    x, w = torch.randn(B, cin, H, W, generator=g), torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    bn_ref = nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        bn_ref.running_mean.copy_(0.1 * torch.randn(cout, generator=g))
+        bn_ref.running_var.copy_(0.5 + torch.rand(cout, generator=g))
+    bn_hip = nn.BatchNorm2d(cout).eval()
+    bn_hip.load_state_dict(bn_ref.state_dict())
+    bn_hip.to(_dev())
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.relu(bn_ref(F.conv2d(xr, wr, padding=1)))
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe).sum().backward()
+    with runtime.precision(torch.float32, 1.0):
+        xd, wd = nhwc(x, torch.float32).requires_grad_(), w.to(_dev()).requires_grad_()
+        cfg = hc._Cfg(hc.ConvSpec(cin, cout, 3, 1, 1), hc.PackedWeights(), bn_hip, True, 1.0)
+        y = hc.ConvBnAct.apply(xd, wd, None, bn_hip.weight, bn_hip.bias, None, cfg, False)
+        (y * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+    close(nchw(y, cout), yr)
+    close(nchw(xd.grad, cin), xr.grad, atol=1e-4)
+    close(wd.grad, wr.grad, atol=2e-4)
+    close(bn_hip.weight.grad, bn_ref.weight.grad, atol=2e-4)
+    close(bn_hip.bias.grad, bn_ref.bias.grad, atol=2e-4)
+    assert int(bn_hip.num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_maxpool_gap_vs_torch(dtype):
+    from self_driving_model_amd.hip import ops as hops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 23, 37, generator=g)
+    x[0, :, 4:6, 4:6] = 1.5  # ties inside windows: first max in scan order must win
+    xq = x.to(dtype).float()
+    xr = xq.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe).sum().backward()
+    xd = nhwc(xq, dtype).requires_grad_()
+    y = hops.MaxPool3x3s2.apply(xd)
+    (y.float() * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+    close(nchw(y, 64), yr, rtol=0, atol=0, what="maxpool fwd is exact")
+    close(nchw(xd.grad, 64), xr.grad, rtol=2e-3 if dtype == torch.float16 else 1e-6, atol=1e-3 if dtype == torch.float16 else 1e-6)
+    # GAP NHWC
+    xr2 = xq.clone().requires_grad_()
+    pr = xr2.mean(dim=(2, 3))
+    p2 = torch.randn(pr.shape, generator=g)
+    (pr * p2).sum().backward()
+    xd2 = nhwc(xq, dtype).requires_grad_()
+    p = hops.GapNhwc.apply(xd2, 1.0)
+    (p * p2.to(_dev())).sum().backward()
+    close(p, pr, rtol=1e-4, atol=1e-5)
+    close(nchw(xd2.grad, 64), xr2.grad, rtol=2e-3, atol=1e-6)
+    # GAP over NCHW planes
+    xr3 = x.clone().requires_grad_()
+    q = F.adaptive_avg_pool2d(xr3, 1).flatten(1)
+    (q * p2).sum().backward()
+    xd3 = x.to(_dev()).requires_grad_()
+    qd = hops.GapPlane.apply(xd3)
+    (qd * p2.to(_dev())).sum().backward()
+    close(qd, q, rtol=1e-4, atol=1e-6)
+    close(xd3.grad, xr3.grad, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 23, 40, 720, 1280), (2, 19, 5, 7, 37, 50), (1, 14, 2, 3, 64, 96)])
+def test_bilinear_vs_torch(shape):
+    from self_driving_model_amd.hip import ops as hops
+    B, C, h, w, H, W = shape
+    g = torch.Generator().manual_seed(8)
+    low = torch.randn(B, C, h, w, generator=g)
+    lr = low.clone().requires_grad_()
+    yr = F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=False)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe).sum().backward()
+    ld = 32 if C % 4 else C
+    ld = max(ld, 16)
+    ld = 32
+    ldv = nhwc(low, torch.float32, ld).requires_grad_()
+    y = hops.BilinearUp.apply(ldv, C, H, W, 1.0)
+    (y * probe.to(_dev())).sum().backward()
+    close(y, yr, rtol=1e-4, atol=1e-5)
+    close(nchw(ldv.grad, C), lr.grad, rtol=1e-3, atol=1e-3)
+    assert float(ldv.grad[..., C:].abs().max()) == 0.0
+
+
+def test_ce2d_vs_torch():
+    from self_driving_model_amd.hip import ops as hops
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 2, 19, 33, 47
+    logits = torch.randn(B, C, H, W, generator=g) * 3
+    tgt = torch.randint(0, C, (B, H, W), generator=g)
+    tgt[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    lr = logits.clone().requires_grad_()
+    loss_r = F.cross_entropy(lr, tgt, ignore_index=255)
+    (loss_r * 1.7).backward()
+    ld = logits.to(_dev()).requires_grad_()
+    loss = hops.CrossEntropy2d.apply(ld, tgt.to(_dev()), 255)
+    (loss * 1.7).backward()
+    close(loss, loss_r, rtol=1e-5, atol=1e-6)
+    close(ld.grad, lr.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_mlp_tail_ops_vs_torch():
+    import torch.nn as nn
+    from self_driving_model_amd.hip import ops as hops
+    g = torch.Generator().manual_seed(10)
+    for (M, K, N, relu) in [(4, 4, 32, True), (32, 768, 512, True), (5, 19, 512, False), (64, 896, 128, True), (3, 128, 3, False)]:
+        x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / np.sqrt(K), torch.randn(N, generator=g)
+        xr, Wr, br = x.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = F.linear(xr, Wr, br)
+        yr = F.relu(yr) if relu else yr
+        probe = torch.randn(M, N, generator=g)
+        (yr * probe).sum().backward()
+        xd, Wd, bd = (t.to(_dev()).requires_grad_() for t in (x, W, b))
+        y = hops.LinearAct.apply(xd, Wd, bd, relu)
+        (y * probe.to(_dev())).sum().backward()
+        close(y, yr, rtol=1e-4, atol=1e-5)
+        close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5)
+        close(Wd.grad, Wr.grad, rtol=1e-4, atol=1e-5)
+        close(bd.grad, br.grad, rtol=1e-4, atol=1e-5)
+    # LayerNorm
+    for (M, D) in [(4, 64), (33, 256)]:
+        x = torch.randn(M, D, generator=g) * 2 + 0.5
+        ln = nn.LayerNorm(D)
+        with torch.no_grad():
+            ln.weight.copy_(1 + 0.1 * torch.randn(D, generator=g))
+            ln.bias.copy_(0.1 * torch.randn(D, generator=g))
+        xr = x.clone().requires_grad_()
+        yr = ln(xr)
+        probe = torch.randn(M, D, generator=g)
+        (yr * probe).sum().backward()
+        xd = x.to(_dev()).requires_grad_()
+        gd, bd = ln.weight.detach().to(_dev()).requires_grad_(), ln.bias.detach().to(_dev()).requires_grad_()
+        y = hops.LayerNormFn.apply(xd, gd, bd, ln.eps)
+        (y * probe.to(_dev())).sum().backward()
+        close(y, yr, rtol=1e-4, atol=1e-5)
+        close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5)
+        close(gd.grad, ln.weight.grad, rtol=1e-4, atol=1e-5)
+        close(bd.grad, ln.bias.grad, rtol=1e-4, atol=1e-5)
+    # dropout: mask statistics and gradient consistency
+    x = torch.ones(64, 512, device=_dev(), requires_grad=True)
+    y = hops.DropoutFn.apply(x, 0.1)
+    keep = float((y > 0).float().mean())
+    assert abs(keep - 0.9) < 0.01
+    assert torch.allclose(y[y > 0], torch.full_like(y[y > 0], 1 / 0.9))
+    y.sum().backward()
+    assert torch.equal(x.grad > 0, y.detach() > 0)
+
+
+@pytest.mark.parametrize("use_softmax,temp,topk,E", [(True, 1.0, 0, 3), (True, 0.5, 0, 4), (False, 1.0, 0, 3), (True, 1.0, 2, 4), (False, 1.0, 2, 4)])
+def test_gate_combine_vs_torch(use_softmax, temp, topk, E):
+    from self_driving_model_amd.hip import ops as hops
+    g = torch.Generator().manual_seed(11)
+    B, D = 6, 256
+    logits = torch.randn(B, E, generator=g)
+    procs = [torch.randn(B, D, generator=g) for _ in range(E)]
+    lr = logits.clone().requires_grad_()
+    pr = [p.clone().requires_grad_() for p in procs]
+    lg = lr
+    if topk:
+        vals, idx = torch.topk(lg, topk, dim=1)
+        lg = torch.full_like(lg, float("-inf")).scatter(1, idx, vals)
+    if use_softmax:
+        wr = F.softmax(lg / temp, dim=1)
+    else:
+        s = torch.sigmoid(lg)
+        wr = s / (s.sum(dim=1, keepdim=True) + 1e-8)
+    cr = sum(wr[:, i:i + 1] * pr[i] for i in range(E))
+    p1, p2 = torch.randn(B, D, generator=g), torch.randn(B, E, generator=g)
+    ((cr * p1).sum() + (wr * p2).sum()).backward()
+    ld = logits.to(_dev()).requires_grad_()
+    pd = [p.to(_dev()).requires_grad_() for p in procs]
+    w, c = hops.GateCombine.apply(ld, temp, use_softmax, topk, *pd)
+    ((c * p1.to(_dev())).sum() + (w * p2.to(_dev())).sum()).backward()
+    close(w, wr, rtol=1e-5, atol=1e-6)
+    close(c, cr, rtol=1e-5, atol=1e-5)
+    close(ld.grad, lr.grad, rtol=1e-4, atol=1e-5)
+    for a, b in zip(pd, pr):
+        close(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(w.sum(dim=1).cpu(), torch.ones(B), atol=1e-6) and bool((w >= 0).all())
+
+
+def test_adamw_and_clip_vs_torch():
+    from self_driving_model_amd.hip import lib
+    from self_driving_model_amd.hip.conv import ptr, stream
+    L = lib.get()
+    g = torch.Generator().manual_seed(12)
+    n = 100_003
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) * 0.01 for _ in range(3)]
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([pr], lr=4e-4, weight_decay=1e-4)
+    pd = p0.to(_dev())
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step, gr in enumerate(grads, 1):
+        pr.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pr], max_norm=1.0)
+        opt.step()
+        gd = gr.to(_dev())
+        acc = torch.zeros(1, dtype=torch.float64, device=_dev())
+        L.am_sumsq_accumulate(ptr(gd), n, ptr(acc), stream())
+        L.am_adamw_step(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 4e-4, 0.9, 0.999, 1e-8, 1e-4, step, 1.0, ptr(acc), None, stream())
+        close(acc.sqrt(), gr.double().norm(), rtol=1e-6, atol=0)
+    close(pd, pr, rtol=1e-5, atol=1e-6)
+    # non-finite norm skips the step and counts it
+    skipped = torch.zeros(1, dtype=torch.int32, device=_dev())
+    acc = torch.full((1,), float("inf"), dtype=torch.float64, device=_dev())
+    before = pd.clone()
+    L.am_adamw_step(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 4e-4, 0.9, 0.999, 1e-8, 1e-4, 4, 1.0, ptr(acc), ptr(skipped), stream())
+    assert torch.equal(pd, before) and int(skipped) == 1

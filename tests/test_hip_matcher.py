@@ -1,0 +1,139 @@
+"""GPU parity tests for the device-side Hungarian matcher: bit-exact indices against the oracle
+(oracle/lsap.c, pinned to scipy) and scipy itself; cost matrix against the torch-CPU restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _solve_gpu(cost_np):
+    from self_driving_model_amd.hip import matcher as hm
+    c = torch.from_numpy(np.ascontiguousarray(cost_np, dtype=np.float32))[None].to(_dev())
+    rows, cols, count, status = hm.lsap_batched(c)
+    k = int(count[0])
+    return rows[0, :k].cpu().numpy(), cols[0, :k].cpu().numpy(), int(status[0])
+
+
+def test_lsap_golden_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lsap_cases.npz"))
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        cost = g[f"{name}/cost"]
+        if cost.size == 0:
+            continue
+        r, c, st = _solve_gpu(cost)
+        assert st == 0, name
+        assert np.array_equal(r, g[f"{name}/rows"]) and np.array_equal(c, g[f"{name}/cols"]), name
+
+
+def test_lsap_random_vs_oracle_and_scipy():
+    from scipy.optimize import linear_sum_assignment
+    from oracle.matcher import lsap_c
+    from self_driving_model_amd.hip import matcher as hm
+    rng = np.random.default_rng(3)
+    # batched, ragged column counts, heavy ties
+    B, nr, ncmax = 16, 300, 40
+    cost = rng.integers(0, 5, size=(B, nr, ncmax)).astype(np.float32)
+    cost[::2] = rng.standard_normal((B // 2, nr, ncmax)).astype(np.float32)
+    ncols = rng.integers(0, ncmax + 1, size=B).astype(np.int32)
+    rows, cols, count, status = hm.lsap_batched(torch.from_numpy(cost).to(_dev()), torch.from_numpy(ncols).to(_dev()))
+    rows, cols, count, status = rows.cpu().numpy(), cols.cpu().numpy(), count.cpu().numpy(), status.cpu().numpy()
+    for b in range(B):
+        sub = cost[b, :, : ncols[b]]
+        r0, c0 = linear_sum_assignment(sub)
+        r1, c1 = lsap_c(sub)
+        assert status[b] == 0 and count[b] == min(nr, ncols[b])
+        assert np.array_equal(rows[b, : count[b]], r0) and np.array_equal(cols[b, : count[b]], c0), b
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+    # wide (rows < cols) and square
+    for shape in [(20, 196), (64, 64), (1, 7), (7, 1)]:
+        m = rng.standard_normal(shape).astype(np.float32)
+        r, c, st = _solve_gpu(m)
+        r0, c0 = linear_sum_assignment(m)
+        assert st == 0 and np.array_equal(r, r0) and np.array_equal(c, c0), shape
+
+
+def test_lsap_invalid_and_infeasible():
+    m = np.zeros((5, 3), dtype=np.float32); m[2, 1] = np.nan
+    assert _solve_gpu(m)[2] == -2
+    m[2, 1] = -np.inf
+    assert _solve_gpu(m)[2] == -2
+    assert _solve_gpu(np.full((3, 3), np.inf, dtype=np.float32))[2] == -1
+    m = np.random.default_rng(0).standard_normal((40, 6)).astype(np.float32); m[::3, 1] = np.inf
+    from scipy.optimize import linear_sum_assignment
+    r, c, st = _solve_gpu(m)
+    r0, c0 = linear_sum_assignment(m)
+    assert st == 0 and np.array_equal(r, r0) and np.array_equal(c, c0)
+
+
+def _random_detection(B, Q, C, nmax, seed, H=720.0, W=1280.0):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, Q, C, generator=g)
+    boxes = torch.randn(B, Q, 4, generator=g) * 50 + 100   # unconstrained predictions: w,h may be negative
+    counts = torch.randint(0, nmax + 1, (B,), generator=g)
+    counts[0] = nmax
+    targets = []
+    for b in range(B):
+        n = int(counts[b])
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([W, H]) * 0.8
+        wh = (0.02 + 0.18 * torch.rand(n, 2, generator=g)) * torch.tensor([W, H])
+        cxcywh = torch.cat([xy + wh / 2, wh], dim=1)
+        targets.append({"boxes": cxcywh, "labels": torch.randint(0, C, (n,), generator=g)})
+    return logits, boxes, targets
+
+
+def test_matcher_module_vs_oracle():
+    from oracle.matcher import HungarianMatcher as OracleMatcher
+    from oracle.matcher import cost_matrix, lsap_c
+    from self_driving_model_amd.hip import matcher as hm
+    from self_driving_model_amd.training import HungarianMatcher
+    B, Q, C, nmax = 8, 920, 10, 32
+    logits, boxes, targets = _random_detection(B, Q, C, nmax, 21)
+    ref = OracleMatcher(1.0, 5.0, 2.0)({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    dev = _dev()
+    m = HungarianMatcher(1.0, 5.0, 2.0)
+    out = m({"pred_logits": logits.to(dev), "pred_boxes": boxes.to(dev)},
+            [{k: v.to(dev) for k, v in t.items()} for t in targets])
+    assert len(out) == B
+    for b in range(B):
+        pi, ti = out[b]
+        assert pi.dtype == torch.int64 and ti.dtype == torch.int64 and pi.device.type == "cuda"
+        assert torch.equal(pi.cpu(), ref[b][0]) and torch.equal(ti.cpu(), ref[b][1]), b
+    # the device cost matrix itself: close to the torch-CPU restatement, and LSAP on it is bit-exact
+    n_tgt = torch.tensor([t["labels"].numel() for t in targets], dtype=torch.int32)
+    lab = torch.full((B, nmax), -1, dtype=torch.int64)
+    bx = torch.zeros(B, nmax, 4)
+    for b, t in enumerate(targets):
+        lab[b, : n_tgt[b]], bx[b, : n_tgt[b]] = t["labels"], t["boxes"]
+    cost = hm.match_cost(logits.to(dev), boxes.to(dev), lab.to(dev), bx.to(dev), n_tgt.to(dev), 1.0, 5.0, 2.0).cpu()
+    for b in range(B):
+        n = int(n_tgt[b])
+        if n == 0:
+            continue
+        cref = cost_matrix(logits[b], boxes[b], targets[b]["labels"], targets[b]["boxes"])
+        got = cost[b, :n].T
+        np.testing.assert_allclose(got.numpy(), cref.numpy(), rtol=1e-4, atol=1e-3)
+        r, c = lsap_c(np.ascontiguousarray(got.numpy()))
+        assert np.array_equal(r, out[b][0].cpu().numpy()) and np.array_equal(c, out[b][1].cpu().numpy())
+
+
+def test_matcher_empty_targets_and_nan():
+    from self_driving_model_amd.training import HungarianMatcher
+    dev = _dev()
+    m = HungarianMatcher()
+    logits, boxes = torch.randn(2, 50, 10, device=dev), torch.randn(2, 50, 4, device=dev)
+    empty = {"boxes": torch.zeros(0, 4, device=dev), "labels": torch.zeros(0, dtype=torch.int64, device=dev)}
+    out = m({"pred_logits": logits, "pred_boxes": boxes}, [empty, empty])
+    assert all(o[0].numel() == 0 and o[1].numel() == 0 and o[0].dtype == torch.int64 for o in out)
+    boxes[0, 3, 2] = float("nan")
+    t = {"boxes": torch.tensor([[10.0, 10.0, 4.0, 4.0]], device=dev), "labels": torch.tensor([1], device=dev)}
+    with pytest.raises(ValueError):
+        m({"pred_logits": logits, "pred_boxes": boxes}, [t, t])
+    with pytest.raises(AssertionError):
+        HungarianMatcher(0, 0, 0)

@@ -1,0 +1,316 @@
+"""GPU parity tests, model level: the drop-in modules (same class names / state_dict keys as the
+reference) against the oracle (oracle/torch_ref.py, torch-CPU fp32) on the same seeded weights and
+inputs, and against the golden vectors generated from the reference itself (tests/golden/*.npz).
+
+fp32 compute mode is held to the north_star tolerance (rtol 1e-3 / atol 1e-5, gradients of deep
+stacks at atol 1e-4); fp16 mode to a relative-L2 bound."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _seeded import seed_module_, seeded_tensor
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-3, 1e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=RT, atol=AT, what=""):
+    np.testing.assert_allclose(a.detach().float().cpu().double().numpy(), torch.as_tensor(b).detach().float().cpu().double().numpy(),
+                               rtol=rtol, atol=atol, err_msg=what)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu().double(), torch.as_tensor(b).detach().float().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _pair(cls_name, seed, *args, **kw):
+    """(hip module on device, oracle module on cpu) with identical seeded weights."""
+    import self_driving_model_amd.models.experts as hx
+    import self_driving_model_amd.models.gating as hg
+    import self_driving_model_amd.models.context as hc
+    import self_driving_model_amd.models.policy.trajectory_head as hp
+    from oracle import torch_ref as oref
+    for mod in (hx, hg, hc, hp):
+        if hasattr(mod, cls_name):
+            hip_cls = getattr(mod, cls_name)
+            break
+    ref = seed_module_(getattr(oref, cls_name)(*args, **kw), seed)
+    hip = hip_cls(*args, **kw)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    return hip.to(_dev()), ref
+
+
+def _grad_check(hip, ref, rtol, atol, skip=()):
+    for (n, p), (n2, q) in zip(hip.named_parameters(), ref.named_parameters()):
+        assert n == n2
+        if any(s in n for s in skip) or q.grad is None:
+            continue
+        assert p.grad is not None, n
+        close(p.grad, q.grad, rtol=rtol, atol=atol, what=n)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_drivable_expert_fp32_vs_oracle(train):
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    from oracle.losses import segmentation_loss
+    hip, ref = _pair("BDDDrivableExpert", 31, 3, False)
+    hip.train(train); ref.train(train)
+    x = seeded_tensor((2, 3, 64, 96), 32)
+    g = torch.Generator().manual_seed(33)
+    mask = torch.randint(0, 3, (2, 64, 96), generator=g)
+    mask[torch.rand(2, 64, 96, generator=g) < 0.05] = 255
+    yr = ref(x)
+    lr = segmentation_loss(yr, mask)
+    lr.backward()
+    with runtime.precision(torch.float32):
+        y = hip(x.to(_dev()))
+        loss = hops.CrossEntropy2d.apply(y, mask.to(_dev()), 255)
+        loss.backward()
+    assert y.shape == (2, 3, 64, 96) and y.dtype == torch.float32
+    close(y, yr, what="logits")
+    close(loss, lr, rtol=1e-4, atol=1e-6, what="loss")
+    _grad_check(hip, ref, RT, 1e-4)
+    if train:
+        for (n, b), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
+            close(b.float(), br.float(), rtol=RT, atol=1e-5, what=n)
+
+
+def test_segmentation_expert_config1_fp32():
+    """BASELINE config 1: segmentation expert forward on one 3x256x256 tensor."""
+    from self_driving_model_amd import runtime
+    hip, ref = _pair("BDDSegmentationExpert", 34, 19, False)
+    hip.eval(); ref.eval()
+    x = seeded_tensor((1, 3, 256, 256), 35)
+    with torch.no_grad():
+        yr = ref(x)
+        with runtime.precision(torch.float32):
+            y = hip(x.to(_dev()))
+    assert y.shape == (1, 19, 256, 256)
+    close(y, yr)
+
+
+def test_detection_expert_fp32_and_fp16():
+    from self_driving_model_amd import runtime
+    hip, ref = _pair("BDDDetectionExpert", 36, 10, False)
+    hip.train(); ref.train()
+    x = seeded_tensor((2, 3, 96, 128), 37)
+    o_r = ref(x)
+    probe_c, probe_b = seeded_tensor(o_r["class_logits"].shape, 38), seeded_tensor(o_r["bbox_deltas"].shape, 39)
+    ((o_r["class_logits"] * probe_c).sum() + (o_r["bbox_deltas"] * probe_b).sum()).backward()
+    sd = {k: v.clone() for k, v in hip.state_dict().items()}
+    with runtime.precision(torch.float32):
+        o = hip(x.to(_dev()))
+        ((o["class_logits"] * probe_c.to(_dev())).sum() + (o["bbox_deltas"] * probe_b.to(_dev())).sum()).backward()
+    assert o["class_logits"].shape == (2, 10, 3, 4) and o["bbox_deltas"].shape == (2, 4, 3, 4)
+    close(o["class_logits"], o_r["class_logits"])
+    close(o["bbox_deltas"], o_r["bbox_deltas"])
+    _grad_check(hip, ref, RT, 2e-4)
+    # fp16 compute on the same weights (running stats restored first)
+    hip.load_state_dict(sd)
+    hip.zero_grad()
+    with runtime.precision(torch.float16, 1024.0):
+        o16 = hip(x.to(_dev()))
+        ((o16["class_logits"] * probe_c.to(_dev())).sum() + (o16["bbox_deltas"] * probe_b.to(_dev())).sum()).backward()
+    assert rel_err(o16["class_logits"], o_r["class_logits"]) < 2e-2
+    gerrs = [rel_err(p.grad, q.grad) for (n, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()) if q.grad.norm() > 1e-6]
+    assert max(gerrs) < 0.1 and float(np.median(gerrs)) < 3e-2, (max(gerrs), float(np.median(gerrs)))
+
+
+@pytest.mark.parametrize("tag,shape,train", [("small_train", (2, 64, 96), True), ("small_eval", (2, 64, 96), False)])
+def test_policy_vs_reference_golden(golden_dir, tag, shape, train):
+    """TrajectoryPolicy against vectors produced by the reference module itself."""
+    from self_driving_model_amd import runtime
+    g = np.load(os.path.join(golden_dir, "policy.npz"))
+    hip, ref = _pair("TrajectoryPolicy", 400, horizon=10, context_dim=256, backbone_dim=512)
+    hip.train(train)
+    B, H, W = shape
+    ctx = seeded_tensor((B, 256), 402).to(_dev()).requires_grad_()
+    with runtime.precision(torch.float32):
+        o = hip(seeded_tensor((B, 3, H, W), 401).to(_dev()), context=ctx)
+        ((o["waypoints"] * seeded_tensor((B, 10, 2), 403).to(_dev())).sum()
+         + (o["speed"] * seeded_tensor((B, 10), 404).to(_dev())).sum()).backward()
+    close(o["waypoints"], g[f"{tag}/waypoints"], atol=1e-4)
+    close(o["speed"], g[f"{tag}/speed"], atol=1e-4)
+    close(ctx.grad, g[f"{tag}/d_ctx"], atol=1e-4)
+    close(hip.backbone.net[0].weight.grad, g[f"{tag}/d_conv0_w"], atol=2e-4)
+    close(hip.backbone.net[1].weight.grad, g[f"{tag}/d_bn0_w"], atol=2e-4)
+    close(hip.backbone.net[1].bias.grad, g[f"{tag}/d_bn0_b"], atol=2e-4)
+    close(hip.backbone.net[10].running_mean, g[f"{tag}/bn3_running_mean"])
+    close(hip.backbone.net[10].running_var, g[f"{tag}/bn3_running_var"])
+    for n, p in hip.named_parameters():
+        close(p.grad.double().sum(), g[f"{tag}/gsum/{n}"], rtol=2e-3, atol=2e-3, what=n)
+        close(p.grad.double().pow(2).sum().sqrt(), g[f"{tag}/gl2/{n}"], rtol=2e-3, atol=1e-4, what=n)
+
+
+def test_policy_hd_eval_vs_reference_golden(golden_dir):
+    from self_driving_model_amd import runtime
+    g = np.load(os.path.join(golden_dir, "policy.npz"))
+    hip, _ = _pair("TrajectoryPolicy", 400, horizon=10, context_dim=256, backbone_dim=512)
+    hip.eval()
+    img, ctx = seeded_tensor((1, 3, 720, 1280), 401).to(_dev()), seeded_tensor((1, 256), 402).to(_dev())
+    with torch.no_grad():
+        with runtime.precision(torch.float32):
+            o = hip(img, context=ctx)
+        with runtime.precision(torch.float16):
+            o16 = hip(img, context=ctx)
+    close(o["waypoints"], g["hd_eval/waypoints"], atol=1e-4)
+    close(o["speed"], g["hd_eval/speed"], atol=1e-4)
+    assert rel_err(o16["waypoints"], g["hd_eval/waypoints"]) < 2e-2
+
+
+GATING_VARIANTS = {
+    "e3": dict(num_experts=3), "e4": dict(num_experts=4),
+    "e3_sigmoid": dict(num_experts=3, use_softmax=False, temperature=1.0),
+    "e3_temp": dict(num_experts=3, temperature=0.5),
+    "e4_topk2": dict(num_experts=4, top_k=2, noise_scale=0.0, apply_topk_at_eval=True),
+}
+
+
+@pytest.mark.parametrize("tag", list(GATING_VARIANTS))
+def test_gating_vs_reference_golden(golden_dir, tag):
+    from self_driving_model_amd.models.gating import GatingNetwork
+    g = np.load(os.path.join(golden_dir, "gating.npz"))
+    kw = GATING_VARIANTS[tag]
+    E = kw["num_experts"]
+    m = GatingNetwork(context_dim=64, expert_output_dims=[256] * E, processed_dim=256, hidden_dim=128, **kw)
+    seed_module_(m, 100 + E).eval()
+    m.to(_dev())
+    xs = [seeded_tensor((4, 256), 200 + i).to(_dev()).requires_grad_() for i in range(E)]
+    ctx = seeded_tensor((4, 64), 300).to(_dev()).requires_grad_()
+    o = m(xs, ctx)
+    ((o["combined_output"] * seeded_tensor((4, 256), 301).to(_dev())).sum()
+     + (o["expert_weights"] * seeded_tensor((4, E), 302).to(_dev())).sum()).backward()
+    close(o["combined_output"], g[f"{tag}/combined_output"], rtol=1e-4)
+    close(o["expert_weights"], g[f"{tag}/expert_weights"], rtol=1e-4)
+    close(o["gate_logits"], g[f"{tag}/gate_logits"], rtol=1e-4)
+    close(torch.stack(o["processed_expert_outputs"]), g[f"{tag}/processed"], rtol=1e-4)
+    close(ctx.grad, g[f"{tag}/d_ctx"], rtol=1e-3)
+    close(torch.stack([x.grad for x in xs]), g[f"{tag}/d_x"], rtol=1e-3)
+    for n, p in m.named_parameters():
+        close(p.grad.double().sum(), g[f"{tag}/gsum/{n}"], rtol=1e-3, atol=1e-4, what=n)
+        close(p.grad.double().pow(2).sum().sqrt(), g[f"{tag}/gl2/{n}"], rtol=1e-3, atol=1e-5, what=n)
+    close(m.get_expert_weights(ctx.detach()), g[f"{tag}/ctx_only_weights"], rtol=1e-4)
+    close(m.get_gating_logits(ctx.detach()), g[f"{tag}/ctx_only_logits"], rtol=1e-4)
+    w = o["expert_weights"].detach().cpu()  # the reference's own invariants (tests/test_gating_network.py:76-80)
+    assert torch.allclose(w.sum(dim=1), torch.ones(4), atol=1e-6) and bool((w >= 0).all())
+
+
+def test_extractors_and_context_vs_reference_golden(golden_dir):
+    import self_driving_model_amd.models.experts as hx
+    from self_driving_model_amd.models.context import SimpleContextExtractor, create_context_extractor
+    g = np.load(os.path.join(golden_dir, "extractors.npz"))
+    dev = _dev()
+    det = seed_module_(hx.DetectionExpertExtractor(256, 10), 500).eval().to(dev)
+    seg = seed_module_(hx.SegmentationExpertExtractor(256, 19), 501).eval().to(dev)
+    drv = seed_module_(hx.DrivableExpertExtractor(256, 3), 502).eval().to(dev)
+    cl, bd = seeded_tensor((3, 10, 6, 10), 510).to(dev).requires_grad_(), seeded_tensor((3, 4, 6, 10), 511).to(dev).requires_grad_()
+    sx, dx = seeded_tensor((3, 19, 24, 40), 512).to(dev).requires_grad_(), seeded_tensor((3, 3, 24, 40), 513).to(dev).requires_grad_()
+    probe = seeded_tensor((3, 256), 514).to(dev)
+    for tag, m, y, ins in (("det", det, det({"class_logits": cl, "bbox_deltas": bd}), (cl, bd)),
+                           ("seg", seg, seg(sx), (sx,)), ("drv", drv, drv(dx), (dx,))):
+        (y * probe).sum().backward()
+        close(y, g[f"{tag}/features"], rtol=1e-4)
+        for i, t in enumerate(ins):
+            close(t.grad, g[f"{tag}/d_in{i}"], rtol=1e-3, atol=1e-6)
+        for n, p in m.named_parameters():
+            close(p.grad.double().sum(), g[f"{tag}/gsum/{n}"], rtol=1e-3, atol=1e-4, what=n)
+    c = seed_module_(SimpleContextExtractor(64), 520).eval().to(dev)
+    ins = [seeded_tensor((5, 1), 521 + i).to(dev).requires_grad_() for i in range(4)]
+    y = c(*ins)
+    (y * seeded_tensor((5, 64), 530).to(dev)).sum().backward()
+    close(y, g["ctx/features"], rtol=1e-4)
+    close(torch.cat([t.grad for t in ins], dim=1), g["ctx/d_in"], rtol=1e-3)
+    assert isinstance(create_context_extractor({"type": "simple", "context_dim": 64}), SimpleContextExtractor)
+    with pytest.raises(ValueError):
+        create_context_extractor({"type": "nope"})
+
+
+AUTOMOE_CFG = {"experts": [{"type": "detection", "num_classes": 10, "output_dim": 256, "pretrained_backbone": False},
+                           {"type": "segmentation", "num_classes": 19, "output_dim": 256, "pretrained_backbone": False},
+                           {"type": "drivable", "num_classes": 3, "output_dim": 256, "pretrained_backbone": False}],
+               "gating": {"processed_dim": 256, "hidden_dim": 128, "temperature": 1.0, "use_softmax": True},
+               "context": {"type": "simple", "context_dim": 64}, "policy": {"num_waypoints": 10}}
+
+
+def _automoe_pair(seed):
+    from oracle import torch_ref as oref
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    ref = seed_module_(oref.create_automoe_model(AUTOMOE_CFG, "cpu"), seed)
+    hip = create_automoe_model(AUTOMOE_CFG, "cpu")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    return hip.to(_dev()), ref
+
+
+def _batch(B, H, W, seed):
+    return {"image": seeded_tensor((B, 3, H, W), seed), "speed": seeded_tensor((B, 10), seed + 1),
+            "steering": seeded_tensor((B, 10), seed + 2), "throttle": seeded_tensor((B, 10), seed + 3),
+            "brake": seeded_tensor((B, 10), seed + 4), "waypoints": seeded_tensor((B, 10, 2), seed + 5)}
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_automoe_train_step_fp32_vs_oracle(frozen):
+    """Config 4 at reduced size: full AutoMoE forward + gating losses + backward, experts frozen (reference
+    default: BN still in train mode) and unfrozen."""
+    from oracle.losses import gating_losses
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.training.train_gating_network import compute_gating_losses
+    hip, ref = _automoe_pair(50)
+    if frozen:
+        hip.freeze_experts(); ref.freeze_experts()
+    hip.train(); ref.train()
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0  # dropout streams differ by construction; everything else is compared
+    batch = _batch(2, 64, 96, 60)
+    cfg = {}
+    o_r = ref(batch)
+    l_r = gating_losses(o_r, batch["waypoints"], batch["speed"], cfg)
+    l_r["total_loss"].backward()
+    with runtime.precision(torch.float32):
+        db = {k: v.to(_dev()) for k, v in batch.items()}
+        o = hip(db)
+        l = compute_gating_losses(o, db["waypoints"], db["speed"], cfg)
+        l["total_loss"].backward()
+    for k in ("waypoints", "speed", "speed_seq", "expert_weights", "context_features", "combined_features", "gate_logits"):
+        close(o[k], o_r[k], what=k)
+    for k in l_r:
+        close(l[k], l_r[k], rtol=1e-4, atol=1e-6, what=k)
+    assert o["speed"].shape == (2, 1)
+    _grad_check(hip, ref, RT, 2e-4)
+    if frozen:
+        assert all(p.grad is None for p in hip.experts.parameters())
+    for (n, b), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
+        close(b.float(), br.float(), rtol=RT, atol=1e-5, what=n)  # frozen experts still update BN running stats
+
+
+def test_automoe_fp16_forward_and_api():
+    from self_driving_model_amd import runtime
+    hip, ref = _automoe_pair(51)
+    hip.eval(); ref.eval()
+    batch = _batch(2, 128, 160, 70)
+    with torch.no_grad():
+        o_r = ref(batch)
+        with runtime.precision(torch.float16):
+            o = hip({k: v.to(_dev()) for k, v in batch.items()})
+    assert set(o.keys()) == {"waypoints", "speed", "speed_seq", "expert_weights", "expert_outputs", "context_features",
+                             "combined_features", "gate_logits"}
+    assert rel_err(o["waypoints"], o_r["waypoints"]) < 3e-2
+    assert rel_err(o["expert_weights"], o_r["expert_weights"]) < 1e-2
+    assert rel_err(o["expert_outputs"][1], o_r["expert_outputs"][1]) < 3e-2
+    w = hip.get_expert_weights({k: v.to(_dev()) for k, v in batch.items()})
+    assert w.shape == (2, 3) and torch.allclose(w.sum(dim=1).cpu(), torch.ones(2), atol=1e-6)
+    hip.freeze_experts()
+    assert not any(p.requires_grad for p in hip.experts.parameters())
+    hip.unfreeze_experts()
+    assert all(p.requires_grad for p in hip.experts.parameters())
+    with pytest.raises(ValueError):
+        hip.load_expert_checkpoints(["a"])
