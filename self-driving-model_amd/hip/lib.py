@@ -60,8 +60,19 @@ def parse_header(path: str = HEADER) -> Dict[str, List[Tuple[str, object]]]:
     return protos
 
 
+def _load_torch_hip_runtime():
+    """libautomoe_hip.so needs libamdhip64.so.7.  PyTorch-ROCm ships its own copy under torch/lib with the same
+    SONAME; the process must use exactly one HIP runtime (streams and device pointers are shared with torch), so
+    torch's copy is loaded first and the dynamic linker then resolves our dependency to it."""
+    import torch  # noqa: F401  (imports torch/lib/libamdhip64.so as a side effect)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 class _Lib:
     def __init__(self):
+        _load_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
