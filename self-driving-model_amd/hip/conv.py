@@ -180,14 +180,50 @@ class PackedWeights:
 # ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
-def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None):
-    import ctypes
-    _L().am_conv_gemm(ctypes.byref(g), dt_code(y.dtype), ptr(x), ptr(wp), ptr(bias), int(relu), ptr(y), ptr(stats), stream())
+class KernelTimer:
+    """Optional per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg).
+    `flops` is the ALGORITHMIC count of the launch, 2*M*K*N with the real (unpadded) K."""
+
+    def __init__(self):
+        self.records = []  # (kind, flops, ev0, ev1)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
 
 
-def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp):
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(kind: str, flops: float, fn):
+    if TIMER is None:
+        fn()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    TIMER.records.append((kind, flops, e0, e1))
+
+
+def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None, k_real: Optional[int] = None, kind: str = "conv_gemm"):
     import ctypes
-    _L().am_conv_wgrad(ctypes.byref(g), dt_code(x.dtype), ptr(x), ptr(dy), float(scale), ptr(dwp), stream())
+    flops = 2.0 * g.B * g.MH * g.MW * (k_real if k_real is not None else g.ntaps * g.krun) * g.N
+    _timed(kind, flops, lambda: _L().am_conv_gemm(ctypes.byref(g), dt_code(y.dtype), ptr(x), ptr(wp), ptr(bias), int(relu),
+                                                  ptr(y), ptr(stats), stream()))
+
+
+def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp, k_real: Optional[int] = None):
+    import ctypes
+    flops = 2.0 * g.B * g.MH * g.MW * (k_real if k_real is not None else g.ntaps * g.krun) * g.N
+    _timed("conv_wgrad", flops, lambda: _L().am_conv_wgrad(ctypes.byref(g), dt_code(x.dtype), ptr(x), ptr(dy), float(scale),
+                                                           ptr(dwp), stream()))
 
 
 class _Cfg:
@@ -219,12 +255,12 @@ class ConvBnAct(torch.autograd.Function):
         raw = alloc((B, OH, OW, ldo), dtype=dtype, device=dev)
         P = B * OH * OW
         if bn is None:
-            conv_gemm(g, x, wp, b, cfg.relu, raw, None)
+            conv_gemm(g, x, wp, b, cfg.relu, raw, None, k_real=s.cin * s.k * s.k)
             y, mean, rstd = raw, None, None
         else:
             use_batch = training or bn.running_mean is None
             stats = torch.zeros(AM_STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=dev) if use_batch else None
-            conv_gemm(g, x, wp, b, False, raw, stats)
+            conv_gemm(g, x, wp, b, False, raw, stats, k_real=s.cin * s.k * s.k)
             scale = torch.empty(cout, dtype=torch.float32, device=dev)
             shift = torch.empty_like(scale)
             mean = torch.empty_like(scale)
@@ -298,11 +334,11 @@ class ConvBnAct(torch.autograd.Function):
             dx = torch.empty_like(x)
             for idx, (gd, taps) in enumerate(dgrad_plans(s, B, IH, IW, ldi, ldo, es)):
                 wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
-                conv_gemm(gd, dz, wd, None, False, dx, None)
+                conv_gemm(gd, dz, wd, None, False, dx, None, k_real=len(taps) * s.cout, kind="conv_dgrad")
         if ctx.needs_input_grad[1]:
             ktot = g.ntaps * g.krun
             dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
-            conv_wgrad(g, x, dz, inv, dwp)
+            conv_wgrad(g, x, dz, inv, dwp, k_real=s.cin * s.k * s.k)
             dw = unpack_wgrad(dwp, s, dtype)
         return dx, dw, db, dgamma, dbeta, dres, None, None
 
