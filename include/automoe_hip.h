@@ -148,6 +148,14 @@ int am_bilinear_up_fwd(int dtype, const void* low, int ld, float* out, int B, in
                        am_stream_t stream);
 int am_bilinear_up_bwd(int dtype, const float* dout, void* dlow, int ld, int B, int C, int h, int w, int H, int W,
                        float mul, const float* dev_scale, am_stream_t stream);
+/* Extractor seam fused: AdaptiveAvgPool2d(1)(F.interpolate(low)) == sum_{y,x} cy[y]*cx[x]*low[b,y,x,c] with
+ * cy/cx = am_bilinear_colsum (column sums of the separable interpolation weights / output size); the full-resolution
+ * logits (70 MB/img for the segmentation expert) are never written.  bwd: dlow = g[b,c]*cy[y]*cx[x]*mul. */
+int am_bilinear_colsum(float* coef, int in_size, int out_size, am_stream_t stream);
+int am_upsample_gap_fwd(int dtype, const void* low, int ld, const float* cy, const float* cx, float* out, int B, int C,
+                        int h, int w, am_stream_t stream);
+int am_upsample_gap_bwd(int dtype, const float* g, const float* cy, const float* cx, void* dlow, int ld, int B, int C,
+                        int h, int w, float mul, am_stream_t stream);
 int am_ce2d_fwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
                 double* acc2, am_stream_t stream);
 int am_ce2d_bwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,

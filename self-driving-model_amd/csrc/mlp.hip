@@ -8,75 +8,101 @@ namespace {
 
 constexpr int MB = 8;  // rows per pass
 
-// y[m][n] = act(sum_k x[m][k] * W[n][k] + b[n]); one wave per output column n
+// y[m][n] = act(sum_k x[m][k] * W[n][k] + b[n]).  One wave per (output column n, chunk of MB rows): grid
+// (ceil(N/4), ceil(M/MB)).  Lanes stride over K with 16-byte loads when the rows allow it, so a wave has
+// (1 + MB) independent float4 loads in flight per iteration; wave64 shuffle reduction per row.
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                     const float* __restrict__ bias, float* __restrict__ y, int ldy, int M, int N,
                                                     int K, int relu) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  const int m0 = blockIdx.y * MB;
   const float* w = W + (size_t)n * K;
-  const float b = bias ? bias[n] : 0.f;
-  for (int m0 = 0; m0 < M; m0 += MB) {
-    float acc[MB];
+  const float* xr[MB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+  for (int i = 0; i < MB; ++i) xr[i] = x + (size_t)min(m0 + i, M - 1) * ldx;  // rows past M alias the last row (discarded)
+  float acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+  if constexpr (VEC) {
+#pragma unroll 2
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr[i] + k);
+        acc[i] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+      }
+    }
+  } else {
     for (int k = lane; k < K; k += 64) {
       const float wv = w[k];
 #pragma unroll
-      for (int i = 0; i < MB; ++i)
-        if (m0 + i < M) acc[i] += wv * x[(size_t)(m0 + i) * ldx + k];
+      for (int i = 0; i < MB; ++i) acc[i] += wv * xr[i][k];
     }
+  }
+  const float b = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      const float s = wave_sum(acc[i]);
-      if (lane == 0 && m0 + i < M) {
-        float v = s + b;
-        if (relu) v = fmaxf(v, 0.f);
-        y[(size_t)(m0 + i) * ldy + n] = v;
-      }
+  for (int i = 0; i < MB; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0 && m0 + i < M) {
+      float v = s + b;
+      if (relu) v = fmaxf(v, 0.f);
+      y[(size_t)(m0 + i) * ldy + n] = v;
     }
   }
 }
 
 // dx[m][k] (+)= sum_n dz[m][n] * W[n][k], dz = dy * (yact > 0) when yact given.
-// block = 64 k-columns x 4 n-slices; grid (ceil(K/64), ceil(M/MB))
-__global__ __launch_bounds__(256) void linear_bwd_input_k(const float* __restrict__ dy, int lddy, const float* __restrict__ yact,
-                                                          int ldya, const float* __restrict__ W, float* __restrict__ dx, int lddx,
-                                                          int M, int N, int K, int accumulate) {
-  __shared__ float red[4][MB][64];
+// block = 64 k-columns x 16 n-slices (1024 threads): dz of the block's MB rows is staged once in LDS (ReLU mask applied),
+// each thread streams its slice of W rows (coalesced across k) against LDS-broadcast dz; LDS reduce over slices.
+constexpr int BI_SLICES = 16;
+__global__ __launch_bounds__(1024) void linear_bwd_input_k(const float* __restrict__ dy, int lddy, const float* __restrict__ yact,
+                                                           int ldya, const float* __restrict__ W, float* __restrict__ dx, int lddx,
+                                                           int M, int N, int K, int accumulate) {
+  extern __shared__ float sm[];            // dz [MB][N] then red [BI_SLICES][MB][64]
+  float* dz = sm;
+  float* red = sm + (size_t)MB * N;
   const int kx = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + kx;
   const int m0 = blockIdx.y * MB;
+  for (int e = threadIdx.x; e < MB * N; e += 1024) {
+    const int i = e / N, n = e - i * N;
+    float g = 0.f;
+    if (m0 + i < M) {
+      g = dy[(size_t)(m0 + i) * lddy + n];
+      if (yact && !(yact[(size_t)(m0 + i) * ldya + n] > 0.f)) g = 0.f;
+    }
+    dz[e] = g;
+  }
+  __syncthreads();
   float acc[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) acc[i] = 0.f;
-  const int nper = (N + 3) / 4;
+  const int nper = (N + BI_SLICES - 1) / BI_SLICES;
   const int nb = slice * nper, ne = min(N, nb + nper);
   if (k < K) {
+#pragma unroll 4
     for (int n = nb; n < ne; ++n) {
       const float wv = W[(size_t)n * K + k];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        if (m0 + i < M) {
-          float g = dy[(size_t)(m0 + i) * lddy + n];
-          if (yact && !(yact[(size_t)(m0 + i) * ldya + n] > 0.f)) g = 0.f;
-          acc[i] += g * wv;
-        }
-      }
+      for (int i = 0; i < MB; ++i) acc[i] += dz[i * N + n] * wv;
     }
   }
 #pragma unroll
-  for (int i = 0; i < MB; ++i) red[slice][i][kx] = acc[i];
+  for (int i = 0; i < MB; ++i) red[(slice * MB + i) * 64 + kx] = acc[i];
   __syncthreads();
-  if (slice == 0 && k < K) {
+  for (int e = threadIdx.x; e < MB * 64; e += 1024) {
+    const int i = e >> 6, kk = e & 63;
+    const int ko = blockIdx.x * 64 + kk;
+    if (m0 + i < M && ko < K) {
+      float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      if (m0 + i < M) {
-        const float v = (red[0][i][kx] + red[1][i][kx]) + (red[2][i][kx] + red[3][i][kx]);
-        float* d = dx + (size_t)(m0 + i) * lddx + k;
-        *d = accumulate ? *d + v : v;
-      }
+      for (int sl = 0; sl < BI_SLICES; ++sl) v += red[(sl * MB + i) * 64 + kk];
+      float* d = dx + (size_t)(m0 + i) * lddx + ko;
+      *d = accumulate ? *d + v : v;
     }
   }
 }
@@ -283,7 +309,9 @@ extern "C" int am_linear_fwd(const float* x, int ldx, const float* W, const floa
                              int K, int relu, am_stream_t stream) {
   if (!x || !W || !y || M < 0 || N <= 0 || K <= 0) return AM_ERR_ARG;
   if (M == 0) return AM_OK;
-  hipLaunchKernelGGL(linear_fwd_k, dim3(am_cdiv(N, 4)), dim3(256), 0, ST(stream), x, ldx, W, bias, y, ldy, M, N, K, relu);
+  const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
+  if (vec) hipLaunchKernelGGL(linear_fwd_k<true>, dim3(am_cdiv(N, 4), am_cdiv(M, MB)), dim3(256), 0, ST(stream), x, ldx, W, bias, y, ldy, M, N, K, relu);
+  else hipLaunchKernelGGL(linear_fwd_k<false>, dim3(am_cdiv(N, 4), am_cdiv(M, MB)), dim3(256), 0, ST(stream), x, ldx, W, bias, y, ldy, M, N, K, relu);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -292,7 +320,12 @@ extern "C" int am_linear_bwd_input(const float* dy, int lddy, const float* yact,
                                    int M, int N, int K, int accumulate, am_stream_t stream) {
   if (!dy || !W || !dx || M < 0 || N <= 0 || K <= 0) return AM_ERR_ARG;
   if (M == 0) return AM_OK;
-  hipLaunchKernelGGL(linear_bwd_input_k, dim3(am_cdiv(K, 64), am_cdiv(M, MB)), dim3(256), 0, ST(stream), dy, lddy, yact, ldya, W, dx, lddx, M, N, K, accumulate);
+  const size_t lds = sizeof(float) * ((size_t)MB * N + (size_t)BI_SLICES * MB * 64);
+  if (lds > 150 * 1024) return AM_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_input_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AM_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(linear_bwd_input_k, dim3(am_cdiv(K, 64), am_cdiv(M, MB)), dim3(1024), lds, ST(stream), dy, lddy, yact, ldya, W, dx, lddx, M, N, K, accumulate);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

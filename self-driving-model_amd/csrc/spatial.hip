@@ -290,6 +290,66 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* __restrict__ 
   for (int i = threadIdx.x; i < w; i += 256) dlow[(((long long)b * h + y) * w + i) * ld + c] = am_from_f32<T>(bins[i] * m);
 }
 
+// ---- global-average-pool of a bilinear upsample, without materialising the upsample ---------------
+// mean_{Y,X} up(low)[b,c,Y,X] = sum_{y,x} cy[y] * cx[x] * low[b,y,x,c]  with cy/cx the column sums of the (separable)
+// interpolation matrices divided by H and W (host-computed with the kernel's own fp32 index arithmetic).
+// One workgroup per image; threads = [pixel lanes][ld channels]; LDS reduce over pixel lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_gap_fwd_k(const T* __restrict__ low, int ld, const float* __restrict__ cy,
+                                                          const float* __restrict__ cx, float* __restrict__ out, int C, int h, int w) {
+  extern __shared__ float red[];  // [256]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lanes = 256 / ld;          // pixel lanes (ld <= 256)
+  const int c = tid % ld, pl = tid / ld;
+  float acc = 0.f;
+  if (pl < lanes) {
+    for (int p = pl; p < h * w; p += lanes) {
+      const int y = p / w, x = p - y * w;
+      acc += cy[y] * cx[x] * am_to_f32(low[((long long)b * h * w + p) * ld + c]);
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * ld + tid];
+    out[(long long)b * C + tid] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_gap_bwd_k(const float* __restrict__ g, const float* __restrict__ cy,
+                                                          const float* __restrict__ cx, T* __restrict__ dlow, int ld, int C, int h,
+                                                          int w, long long total, float mul) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    const long long bp = i / ld;
+    const int p = (int)(bp % (h * w));
+    const long long b = bp / (h * w);
+    const int y = p / w, x = p - y * w;
+    dlow[i] = am_from_f32<T>(c < C ? g[b * C + c] * cy[y] * cx[x] * mul : 0.f);
+  }
+}
+
+// interpolation column sums, one thread: coef[i] = (1/out) * sum_{dst} weight of source i for dst
+__global__ void bilinear_colsum_k(float* __restrict__ coef, int in_size, int out_size) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float scale = (float)in_size / (float)out_size;
+  for (int i = 0; i < in_size; ++i) coef[i] = 0.f;
+  // fp64 accumulation of the kernel's fp32 weights, rounded once
+  // (in_size <= a few hundred: serial is fine, this runs once per shape and is cached by the caller)
+  extern __shared__ double acc[];
+  for (int i = 0; i < in_size; ++i) acc[i] = 0.0;
+  for (int d = 0; d < out_size; ++d) {
+    int i0, i1;
+    float l1;
+    src_index(d, scale, in_size, i0, i1, l1);
+    acc[i0] += (double)(1.f - l1);
+    acc[i1] += (double)l1;
+  }
+  for (int i = 0; i < in_size; ++i) coef[i] = (float)(acc[i] / (double)out_size);
+}
+
 // ---- pixel-wise cross entropy over NCHW fp32 logits with ignore_index ------------------------
 // fwd: acc[0] += sum of -log softmax[target] over valid pixels (fp64), acc[1] += count
 __global__ __launch_bounds__(256) void ce2d_fwd_k(const float* __restrict__ logits, const long long* __restrict__ target, int C,
@@ -487,6 +547,34 @@ extern "C" int am_ce2d_bwd(const float* logits, const long long* target, int B, 
   const long long total = HW * B;
   if (total == 0) return AM_OK;
   hipLaunchKernelGGL(ce2d_bwd_k, dim3(ew_grid(total)), dim3(256), 0, ST(stream), logits, target, C, HW, total, ignore_index, acc2, grad_out, dlogits);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bilinear_colsum(float* coef, int in_size, int out_size, am_stream_t stream) {
+  if (!coef || in_size <= 0 || out_size <= 0 || in_size > 4096) return AM_ERR_ARG;
+  hipLaunchKernelGGL(bilinear_colsum_k, dim3(1), dim3(64), sizeof(double) * (size_t)in_size, ST(stream), coef, in_size, out_size);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_upsample_gap_fwd(int dtype, const void* low, int ld, const float* cy, const float* cx, float* out, int B, int C,
+                                   int h, int w, am_stream_t stream) {
+  if (!DT_OK(dtype) || !low || !cy || !cx || !out || C > ld || ld > 256 || h <= 0 || w <= 0) return AM_ERR_ARG;
+  if (B == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(upsample_gap_fwd_k<half_t>, dim3(B), dim3(256), 256 * sizeof(float), ST(stream), (const half_t*)low, ld, cy, cx, out, C, h, w);
+  else hipLaunchKernelGGL(upsample_gap_fwd_k<float>, dim3(B), dim3(256), 256 * sizeof(float), ST(stream), (const float*)low, ld, cy, cx, out, C, h, w);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_upsample_gap_bwd(int dtype, const float* g, const float* cy, const float* cx, void* dlow, int ld, int B, int C,
+                                   int h, int w, float mul, am_stream_t stream) {
+  if (!DT_OK(dtype) || !g || !cy || !cx || !dlow || C > ld || h <= 0 || w <= 0) return AM_ERR_ARG;
+  const long long total = (long long)B * h * w * ld;
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(upsample_gap_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), g, cy, cx, (half_t*)dlow, ld, C, h, w, total, mul);
+  else hipLaunchKernelGGL(upsample_gap_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), g, cy, cx, (float*)dlow, ld, C, h, w, total, mul);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

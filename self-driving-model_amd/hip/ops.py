@@ -146,6 +146,42 @@ class BilinearUp(torch.autograd.Function):
         return dlow, None, None, None, None
 
 
+_COLSUM_CACHE = {}
+
+
+def _colsum(in_size: int, out_size: int, device) -> torch.Tensor:
+    key = (in_size, out_size, str(device))
+    if key not in _COLSUM_CACHE:
+        c = torch.empty(in_size, dtype=torch.float32, device=device)
+        _L().am_bilinear_colsum(ptr(c), in_size, out_size, stream())
+        _COLSUM_CACHE[key] = c
+    return _COLSUM_CACHE[key]
+
+
+class UpsampleGap(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1)(F.interpolate(low, (H,W), bilinear)) -> [B,C] fp32 straight from the low-resolution NHWC
+    logits: the mean of a bilinear upsample is a fixed separable weighted sum of the low-resolution map."""
+
+    @staticmethod
+    def forward(ctx, low, C: int, H: int, W: int, loss_scale: float):
+        B, h, w, ld = low.shape
+        cy, cx = _colsum(h, H, low.device), _colsum(w, W, low.device)
+        out = torch.empty((B, C), dtype=torch.float32, device=low.device)
+        _L().am_upsample_gap_fwd(dt_code(low.dtype), ptr(low), ld, ptr(cy), ptr(cx), ptr(out), B, C, h, w, stream())
+        ctx.meta = (low.dtype, B, C, h, w, ld, loss_scale)
+        ctx.save_for_backward(cy, cx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cy, cx = ctx.saved_tensors
+        dtype, B, C, h, w, ld, ls = ctx.meta
+        g = g.contiguous()
+        dlow = torch.empty((B, h, w, ld), dtype=dtype, device=g.device)
+        _L().am_upsample_gap_bwd(dt_code(dtype), ptr(g), ptr(cy), ptr(cx), ptr(dlow), ld, B, C, h, w, float(ls), stream())
+        return dlow, None, None, None, None
+
+
 class CrossEntropy2d(torch.autograd.Function):
     """nn.CrossEntropyLoss(ignore_index) on [B,C,H,W] fp32 logits / [B,H,W] int64 targets -> scalar (mean over
     valid pixels).  The valid count never leaves the device."""

@@ -82,9 +82,10 @@ class Flatten(nn.Flatten):
 class MLPSequential(nn.Sequential):
     """nn.Sequential whose Linear -> ReLU pairs run as one fused kernel."""
 
-    def forward(self, x):
+    def forward(self, x, start: int = 0):
+        """`start` skips leading modules (the fused upsample+pool path enters the extractor MLP after its pooling)."""
         mods = list(self)
-        i = 0
+        i = start
         while i < len(mods):
             m = mods[i]
             if isinstance(m, Linear):

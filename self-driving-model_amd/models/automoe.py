@@ -48,6 +48,10 @@ class AutoMoE(nn.Module):
         self.context_extractor = create_context_extractor(context_config)
         self.gating_network = self._create_gating_network()
         self.policy_head = self._create_policy_head()
+        # When True, segmentation / drivable experts feed their extractor through the fused upsample+average-pool
+        # kernel (identical features, no 70 MB/img logits round trip); `expert_outputs` then holds their LOW-RES
+        # [B,C,h,w] logits instead of the upsampled ones.  Default False = the reference's dict contents exactly.
+        self.fuse_expert_pooling = False
         self.to(device)
 
     def _create_experts(self) -> nn.ModuleList:
@@ -113,11 +117,27 @@ class AutoMoE(nn.Module):
                                         device=batch["image"].device))
         return outs
 
+    def _run_experts_fused(self, batch, nhwc):
+        outs, feats = [], []
+        for i, (expert, extractor) in enumerate(zip(self.experts, self.expert_extractors.extractors)):
+            if hasattr(expert, "pooled_logits"):
+                pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
+                feats.append(extractor.feature_extractor(pooled, start=2))  # skip pool + flatten
+                outs.append(low.detach()[..., : expert.num_classes].permute(0, 3, 1, 2))
+            else:
+                out = expert(batch["image"], nhwc_input=nhwc)
+                outs.append(out)
+                feats.append(extractor(out))
+        return outs, feats
+
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         context_features = self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
-        expert_outputs = self._run_experts(batch, nhwc)
-        expert_features = self.expert_extractors.extract_features(expert_outputs)
+        if self.fuse_expert_pooling:
+            expert_outputs, expert_features = self._run_experts_fused(batch, nhwc)
+        else:
+            expert_outputs = self._run_experts(batch, nhwc)
+            expert_features = self.expert_extractors.extract_features(expert_outputs)
         gating_output = self.gating_network(expert_features, context_features)
         policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc)
         speed_seq = policy_output.get("speed")

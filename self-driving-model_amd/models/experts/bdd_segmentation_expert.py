@@ -22,6 +22,13 @@ class _DenseExpert(nn.Module):
         h = conv_bn_act(f, self.decoder[0], None, relu=True)
         return conv_bn_act(h, self.decoder[2], None, relu=False)  # [B,h,w,ld]
 
+    def pooled_logits(self, x, nhwc_input=None):
+        """AdaptiveAvgPool2d(1)(forward(x)) -> [B,C] without materialising the full-resolution logits, plus the
+        low-resolution NHWC logits it was computed from (exact up to fp rounding)."""
+        xin = nhwc_input if nhwc_input is not None else hops.image_to_nhwc(x, runtime.compute_dtype())
+        low = self.lowres_nhwc(xin)
+        return hops.UpsampleGap.apply(low, self.num_classes, x.shape[-2], x.shape[-1], runtime.loss_scale()), low
+
     def forward(self, x, nhwc_input=None):
         xin = nhwc_input if nhwc_input is not None else hops.image_to_nhwc(x, runtime.compute_dtype())
         low = self.lowres_nhwc(xin)

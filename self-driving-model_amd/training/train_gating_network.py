@@ -69,6 +69,8 @@ class GatingTrainStep:
         self.model = model
         self.core = model.module if hasattr(model, "module") else model
         self.config = config
+        if hasattr(self.core, "fuse_expert_pooling"):
+            self.core.fuse_expert_pooling = bool(config.get("fuse_expert_pooling", True))  # the step never reads expert_outputs
         params = [p for p in self.core.parameters() if p.requires_grad]
         self.optimizer = FusedAdamW(params, lr=config.get("learning_rate", 1e-4), weight_decay=config.get("weight_decay", 1e-4),
                                     max_norm=1.0)

@@ -366,3 +366,36 @@ def test_automoe_fp16_forward_and_api():
     assert all(p.requires_grad for p in hip.experts.parameters())
     with pytest.raises(ValueError):
         hip.load_expert_checkpoints(["a"])
+
+
+def test_fused_upsample_pool_matches_unfused_and_oracle():
+    """mean(bilinear_upsample(low)) as a separable weighted sum -- features and gradients must equal the
+    materialised path and the oracle."""
+    from self_driving_model_amd import runtime
+    hip, ref = _automoe_pair(52)
+    hip.train(); ref.train()
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = _batch(2, 96, 160, 80)
+    o_r = ref(batch)
+    (o_r["waypoints"].sum() + o_r["expert_weights"][:, 0].sum()).backward()
+    sd = {k: v.clone() for k, v in hip.state_dict().items()}
+    res = {}
+    for fused in (False, True):
+        hip.load_state_dict(sd)
+        hip.zero_grad()
+        hip.fuse_expert_pooling = fused
+        with runtime.precision(torch.float32):
+            o = hip({k: v.to(_dev()) for k, v in batch.items()})
+            (o["waypoints"].sum() + o["expert_weights"][:, 0].sum()).backward()
+        res[fused] = (o, {n: p.grad.clone() for n, p in hip.named_parameters() if p.grad is not None})
+    o_u, g_u = res[False]
+    o_f, g_f = res[True]
+    for k in ("waypoints", "expert_weights", "combined_features", "gate_logits"):
+        close(o_f[k], o_r[k], what=k)
+        close(o_f[k], o_u[k], rtol=1e-4, atol=1e-6, what=k)
+    assert o_f["expert_outputs"][1].shape == (2, 19, 3, 5) and o_u["expert_outputs"][1].shape == (2, 19, 96, 160)
+    for n in ("experts.1.decoder.2.weight", "experts.2.decoder.0.weight", "expert_extractors.extractors.1.feature_extractor.2.weight",
+              "experts.1.backbone.7.1.conv2.weight"):
+        close(g_f[n], g_u[n], rtol=2e-3, atol=1e-5, what=n)
