@@ -15,6 +15,7 @@
 // read from LDS with the hardware transpose read ds_read_b64_tr_b16 (f16) or plain b32 (f32).
 // Split over pixel chunks, fp32 atomic accumulation into dW.
 #include "am_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -216,21 +217,59 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
       atomicAdd(st + g.N + n0 + tid, q);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    // f16: stage the wave's output tile in LDS and write it out as whole 16-byte chunks of pixel rows.  (Direct
+    // stores from the MFMA layout are 2 bytes per lane, 64 B per row segment: measured ~1 TB/s, the largest single
+    // cost of the kernel.)  Pad columns (N..round_up(N,8)) receive exact zeros: zero weights, zero bias.
+    constexpr int SP = TN * 64 + 16;  // staging row pitch in bytes
+    __syncthreads();                  // stats scratch / last K-step reads are done
+    char* stg = smem + wid * (TM * 32) * SP;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
-    const bool colok = col < g.N;
-    const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+      const float bv = (p.bias != nullptr && col < g.N) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int op = opix_s[row];
-        float v = acc[tm][tn][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (op >= 0 && colok) y[(size_t)op * g.ldo + g.y_coff + col] = am_from_f32<T>(v);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          float v = acc[tm][tn][r] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
+        }
+    }
+    // the wave reads back what its own lanes wrote: LDS executes a wave's accesses in order, so draining the
+    // writes is enough; the asm also stops the compiler from moving the (differently typed) reads above the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPRW = TN * 4;  // 16-byte chunks per staged row
+    const int ncols = (g.N + 7) & ~7;
+#pragma unroll
+    for (int it = 0; it < TM * TN * 2; ++it) {
+      const int q = it * 64 + lane;
+      const int row = q / CPRW, cc = q - row * CPRW;
+      const int op = opix_s[wm * TM * 32 + row];
+      const int col0 = n0 + wn * TN * 32 + cc * 8;
+      if (op >= 0 && col0 < ncols)
+        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+      const bool colok = col < g.N;
+      const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int op = opix_s[row];
+          float v = acc[tm][tn][r] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (op >= 0 && colok) y[(size_t)op * g.ldo + g.y_coff + col] = am_from_f32<T>(v);
+        }
+    }
   }
 }
 
@@ -448,6 +487,17 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 }  // namespace
 
+int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+                      hipStream_t s);  // conv_gemm2.hip
+int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+                          hipStream_t s);  // conv_patch.hip
+
+static bool use_v1_only() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AM_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;
   if (N > 32) return 64;
@@ -471,6 +521,16 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   p.relu = relu;
   p.mtiles = p.ntiles = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == AM_F16 && !use_v1_only()) {
+    // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
+    rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+    // small-M, deep-K layers (layer4, heads): the LDS-DMA kernel wins; large-M layers stay on the register-staged one
+    if ((long long)p.M <= 65536) {
+      rc = am_conv_gemm2_f16(g, x, w, bias, relu, y, stats, s);
+      if (rc != AM_ERR_UNSUPPORTED) return rc;
+    }
+  }
   return dtype == AM_F16 ? dispatch_conv<half_t>(p, s) : dispatch_conv<float>(p, s);
 }
 

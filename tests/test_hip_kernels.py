@@ -373,3 +373,27 @@ def test_adamw_and_clip_vs_torch():
     before = pd.clone()
     L.am_adamw_step(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 4e-4, 0.9, 0.999, 1e-8, 1e-4, 4, 1.0, ptr(acc), ptr(skipped), stream())
     assert torch.equal(pd, before) and int(skipped) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 180, 320), (3, 45, 64), (1, 200, 333)])
+def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
+    """The 64->64 3x3 patch kernel (conv_patch.hip) takes over from the gather-GEMM for large fp16 problems: same
+    results, including BatchNorm statistics that must exclude the out-of-image rows of edge tiles."""
+    from self_driving_model_amd.hip import conv as hc
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, 64, H, W, generator=g).half().float()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
+    yr = F.conv2d(x, w, padding=1)
+    s = hc.ConvSpec(64, 64, 3, 1, 1)
+    xd = nhwc(x, torch.float16)
+    wp = hc.pack_fwd(w.to(_dev()), s, torch.float16)
+    y = torch.zeros(B, H, W, 64, dtype=torch.float16, device=_dev())
+    stats = torch.zeros(16 * 2 * 64, dtype=torch.float64, device=_dev())
+    geom = hc.fwd_geom(s, B, H, W, 64, 64, 2)
+    hc.conv_gemm(geom, xd, wp, None, False, y, stats)
+    torch.cuda.synchronize()
+    close(nchw(y, 64), yr, rtol=2e-3, atol=2e-3)
+    st = stats.view(16, 2, 64).sum(0).cpu()
+    np.testing.assert_allclose(st[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=0.5)
+    np.testing.assert_allclose(st[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
