@@ -147,16 +147,20 @@ def main():
         "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] variant 4a: full AutoMoE (det+seg+drv ResNet-18 experts frozen, gating, "
                                "policy) train step, 3x720x1280", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}", "loss_scale": runtime.loss_scale(), "optimizer": "AdamW(4e-4,1e-4)+clip1.0"},
+                   "parallelism": f"dp{world}", "loss_scale": runtime.loss_scale(), "optimizer": "AdamW(4e-4,1e-4)+clip1.0",
+                   "hipgraph": step._graph is not None, "fused_expert_pooling": bool(model.fuse_expert_pooling)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- roofline of the dominant kernel family: conv gather-GEMM, per-launch HIP events on the launch stream ----
+        saved = (step._graph, step.use_graph)  # per-launch events need eager launches, not a graph replay
+        step._graph, step.use_graph = None, False
         hconv.TIMER = hconv.KernelTimer()
         for _ in range(2):
             run()
         summ = hconv.TIMER.summary()
         hconv.TIMER = None
+        step._graph, step.use_graph = saved
         fam = summ.get("conv_gemm", {"flops": 0.0, "ms": 1.0, "launches": 0})
         ach = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
@@ -174,7 +178,7 @@ def main():
             others["cfg2_drivable_expert_train_B16_img_s"] = bench_drivable(16, 5, 2)
             model.unfreeze_experts()
             step_b = GatingTrainStep(model, TRAIN_CFG)
-            dt_b = timed_steps(lambda: step_b(batch), 3, 1, False)
+            dt_b = timed_steps(lambda: step_b(batch), 3, 4, False)  # warm-up covers the hipGraph capture
             others["cfg4b_unfrozen_B32_img_s"] = round(args.batch * 3 / dt_b, 2)
         except Exception as e:  # noqa: BLE001
             others["error"] = repr(e)[:200]

@@ -78,6 +78,14 @@ int am_conv_npad(int N);
 int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w, const float* bias,
                  int relu, void* y, double* stats, am_stream_t stream);
 
+/* Fused first layer for frozen (no-gradient) stems in train-mode BatchNorm, f16, space-to-depth geometry only
+ * (conv -> BatchNorm2d(batch statistics) -> ReLU of bdd_*_expert.py:9-11 without writing the raw conv output):
+ *   mode 1: accumulate the BatchNorm statistics of the conv output into `stats`, write nothing;
+ *   mode 2: y = relu(conv * scale[n] + shift[n]) with scale/shift from am_bn_finalize.
+ * Returns AM_ERR_UNSUPPORTED when the geometry / size is not covered (caller uses am_conv_gemm + am_bn_apply). */
+int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
+                        const float* shift, void* y, double* stats, am_stream_t stream);
+
 /* Weight gradient of the same gather-GEMM (torch conv2d backward w.r.t. weight):
  *   dw[n, t*krun + r] += scale * sum_m dy[m, n] * gather(m, t, r),  fp32, atomically accumulated,
  * dw row-major [>=N rows][ntaps*krun] (caller zeroes it, e.g. zero_grad).  `dy` is read at the
@@ -133,6 +141,10 @@ int am_bias_relu_bwd(int dtype, const void* dy, int lddy, const void* yout, int 
  * ------------------------------------------------------------------------------------------ */
 int am_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ld, float mul,
                     am_stream_t stream);
+/* Image boundary for the 3-channel first layers: NCHW fp32 [B,C,H,W] (H, W even) -> space-to-depth(2) NHWC
+ * [B,H/2,W/2,16] `dtype`, channel (py*2+px)*C + c = img[b,c,2Y+py,2X+px].  A stride-2 KxK conv on the image becomes a
+ * stride-1 conv with 16 input channels on this tensor (7x7 -> 4x4 taps, 5x5 -> 3x3 taps). */
+int am_image_s2d(int dtype, const float* src, void* dst, int B, int C, int H, int W, am_stream_t stream);
 int am_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int ld, float mul,
                     am_stream_t stream);
 int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int B, int IH, int IW, int C,
@@ -187,8 +199,9 @@ int am_gate_combine_fwd(const float* logits, const float* const* processed, int 
 int am_gate_combine_bwd(const float* logits, const float* const* processed, int E, int ldp, float temperature,
                         int use_softmax, int top_k, const float* dcombined, const float* dweights_ext,
                         float* dlogits, float* const* dprocessed, int B, int D, am_stream_t stream);
+/* dev_step (optional device int64): mixed into the seed on the device, so a captured hipGraph draws a fresh mask per replay */
 int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, unsigned long long seed,
-                   am_stream_t stream);
+                   const long long* dev_step, am_stream_t stream);
 int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, am_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

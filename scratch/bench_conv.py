@@ -27,14 +27,18 @@ dev = torch.device("cuda:0")
 print(f"B={B}")
 tot_ms = tot_fl = 0
 for name, s, IH, IW in layers:
-    ldi = 8 if s.first else s.cin
-    x = torch.randn(B, IH, IW, ldi, device=dev).to(dt)
+    ldi = 16 if s.first else s.cin
+    if s.first:
+        x = torch.randn(B, IH // 2, IW // 2, 16, device=dev).to(dt)
+    else:
+        x = torch.randn(B, IH, IW, ldi, device=dev).to(dt)
     w = torch.randn(s.cout, s.cin, s.k, s.k, device=dev) * 0.05
     wp = hc.pack_fwd(w, s, dt)
     OH, OW = hc.out_size(IH, s), hc.out_size(IW, s)
+    gIH, gIW = (IH // 2, IW // 2) if s.first else (IH, IW)
     y = torch.empty(B, OH, OW, s.cout, device=dev, dtype=dt)
     stats = torch.zeros(16 * 2 * s.cout, dtype=torch.float64, device=dev)
-    g = hc.fwd_geom(s, B, IH, IW, ldi, s.cout, 2)
+    g = hc.fwd_geom(s, B, gIH, gIW, ldi, s.cout, 2, orig_hw=(IH, IW))
     for _ in range(3):
         hc.conv_gemm(g, x, wp, None, False, y, stats)
     torch.cuda.synchronize()

@@ -489,6 +489,8 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                       hipStream_t s);  // conv_gemm2.hip
+int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
+                    const float* shift, int relu, void* y, double* stats, hipStream_t s);  // conv_s2d.hip
 int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                           hipStream_t s);  // conv_patch.hip
 
@@ -522,6 +524,9 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   p.mtiles = p.ntiles = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16 && !use_v1_only()) {
+    // 3-channel first layers on the space-to-depth image: weights-stationary patch kernel
+    rc = am_conv_s2d_f16(g, 0, x, w, bias, nullptr, nullptr, relu, y, stats, s);
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
     rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
@@ -556,4 +561,13 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
     return launch_wgrad<half_t, 64, 4>(p, s);
   }
   return launch_wgrad<float, 64, 4>(p, s);
+}
+
+extern "C" int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
+                                   const float* shift, void* y, double* stats, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
+  if (!x || !w || (mode == 1 && !stats) || (mode == 2 && (!y || !scale || !shift)) || (mode != 1 && mode != 2)) return AM_ERR_ARG;
+  return am_conv_s2d_f16(g, mode, x, w, nullptr, scale, shift, 1, y, stats, static_cast<hipStream_t>(stream));
 }

@@ -277,7 +277,9 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned l
 }
 
 __global__ __launch_bounds__(256) void dropout_fwd_k(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
-                                                     long long n, float p, unsigned long long seed) {
+                                                     long long n, float p, unsigned long long seed,
+                                                     const long long* __restrict__ dev_step) {
+  if (dev_step) seed += (unsigned long long)dev_step[0] * 0xD1B54A32D192ED03ULL;  // per-step stream under graph replay
   const float inv = 1.f / (1.f - p);
   const unsigned thr = (unsigned)((double)p * 4294967296.0);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -383,10 +385,10 @@ extern "C" int am_gate_combine_bwd(const float* logits, const float* const* proc
 }
 
 extern "C" int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, unsigned long long seed,
-                              am_stream_t stream) {
+                              const long long* dev_step, am_stream_t stream) {
   if (!x || !y || !mask || n < 0 || p < 0.f || p >= 1.f) return AM_ERR_ARG;
   if (n == 0) return AM_OK;
-  hipLaunchKernelGGL(dropout_fwd_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), x, y, mask, n, p, seed);
+  hipLaunchKernelGGL(dropout_fwd_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), x, y, mask, n, p, seed, dev_step);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

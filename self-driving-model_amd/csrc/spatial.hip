@@ -30,6 +30,38 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ 
   }
 }
 
+// ---- image boundary: NCHW fp32 [B,C<=4,H,W] (H, W even) -> space-to-depth(2) NHWC [B,H/2,W/2,16] ------------------
+// channel (py*2+px)*C + c of output pixel (Y,X) = img[b,c,2Y+py,2X+px]; channels 4*C..15 are zero.  A stride-2 KxK
+// first-layer conv on the image is a stride-1 ceil(K/2)+... conv on this tensor with 16 input channels, which gives the
+// MFMA kernels 32-byte (f16) pixels instead of 3 useful channels out of 8.
+template <typename T>
+__global__ __launch_bounds__(256) void image_s2d_k(const float* __restrict__ src, T* __restrict__ dst, int C, int H, int W,
+                                                   long long total) {
+  const int H2 = H / 2, W2 = W / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W2);
+    long long t = i / W2;
+    const int Y = (int)(t % H2);
+    const long long b = t / H2;
+    T out[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = am_from_f32<T>(0.f);
+    for (int c = 0; c < C; ++c) {
+      const float* pl = src + ((b * C + c) * H + 2 * Y) * (long long)W + 2 * X;
+      const float2 r0 = *reinterpret_cast<const float2*>(pl);
+      const float2 r1 = *reinterpret_cast<const float2*>(pl + W);
+      out[0 * C + c] = am_from_f32<T>(r0.x);
+      out[1 * C + c] = am_from_f32<T>(r0.y);
+      out[2 * C + c] = am_from_f32<T>(r1.x);
+      out[3 * C + c] = am_from_f32<T>(r1.y);
+    }
+    uint4* d = reinterpret_cast<uint4*>(dst + i * 16);
+    const uint4* o = reinterpret_cast<const uint4*>(out);
+#pragma unroll
+    for (int e = 0; e < (int)(16 * sizeof(T) / 16); ++e) d[e] = o[e];
+  }
+}
+
 // ---- NHWC T -> NCHW fp32 (first C channels) -------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src, float* __restrict__ dst, int C, long long HW,
@@ -575,6 +607,16 @@ extern "C" int am_upsample_gap_bwd(int dtype, const float* g, const float* cy, c
   if (total == 0) return AM_OK;
   if (dtype == AM_F16) hipLaunchKernelGGL(upsample_gap_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), g, cy, cx, (half_t*)dlow, ld, C, h, w, total, mul);
   else hipLaunchKernelGGL(upsample_gap_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), g, cy, cx, (float*)dlow, ld, C, h, w, total, mul);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_image_s2d(int dtype, const float* src, void* dst, int B, int C, int H, int W, am_stream_t stream) {
+  if (!DT_OK(dtype) || !src || !dst || C < 1 || C > 4 || (H & 1) || (W & 1) || B < 0) return AM_ERR_ARG;
+  const long long total = (long long)B * (H / 2) * (W / 2);
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(image_s2d_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (half_t*)dst, C, H, W, total);
+  else hipLaunchKernelGGL(image_s2d_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (float*)dst, C, H, W, total);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

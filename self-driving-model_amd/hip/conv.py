@@ -20,6 +20,11 @@ def _L():
     return _lib.get()
 
 
+def _runtime():
+    from .. import runtime
+    return runtime
+
+
 def dt_code(dtype: torch.dtype) -> int:
     if dtype == torch.float16:
         return AM_F16
@@ -42,9 +47,43 @@ def require_hip(t: torch.Tensor, what: str = "tensor"):
                            f"there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
 
 
-def image_channels(dtype: torch.dtype) -> int:
-    """Channel padding of a 3-channel image: 16 bytes per pixel."""
-    return 16 // torch.empty((), dtype=dtype).element_size()
+S2D_CH = 16  # channels of the space-to-depth(2) image handed to the 3-channel first layers (12 used)
+
+
+def first_layer_taps(s: "ConvSpec"):
+    """A stride-2 KxK/pad-p conv on the image == a stride-1 TAPSxTAPS conv on the space-to-depth(2) image.
+    Returns (off0, taps): s2d row/col offsets of the first tap and the number of taps per axis."""
+    assert s.stride == 2 and s.cin <= 4
+    off0 = -((s.pad + 1) // 2)
+    taps = (s.k - 1 - s.pad) // 2 - off0 + 1
+    assert 1 <= taps <= 4, "first-layer kernel larger than 8x8 is not supported"
+    return off0, taps
+
+
+_FIRST_INDEX_CACHE = {}
+
+
+def _first_index(s: "ConvSpec", device):
+    """LongTensor [taps*4*16] of flat indices into w[n] (= [cin,k,k] flattened), -1 for structural zeros:
+    packed position (i, j, (py*2+px)*cin + c) <- w[n, c, 2*(off0+i)+py+pad, 2*(off0+j)+px+pad]."""
+    key = (s, str(device))
+    if key not in _FIRST_INDEX_CACHE:
+        import numpy as np
+        off0, taps = first_layer_taps(s)
+        idx = -np.ones((taps, 4, S2D_CH), dtype=np.int64)
+        for i in range(taps):
+            for j in range(taps):
+                for py in range(2):
+                    for px in range(2):
+                        kh, kw = 2 * (off0 + i) + py + s.pad, 2 * (off0 + j) + px + s.pad
+                        if 0 <= kh < s.k and 0 <= kw < s.k:
+                            for c in range(s.cin):
+                                idx[i, j, (py * 2 + px) * s.cin + c] = (c * s.k + kh) * s.k + kw
+        flat = idx.reshape(-1)
+        pos = np.nonzero(flat >= 0)[0]
+        _FIRST_INDEX_CACHE[key] = (torch.from_numpy(flat).to(device), torch.from_numpy(pos).to(device),
+                                   torch.from_numpy(flat[pos]).to(device))
+    return _FIRST_INDEX_CACHE[key]
 
 
 @dataclass(frozen=True)
@@ -77,14 +116,17 @@ def _geom(**kw) -> ConvGeom:
     return g
 
 
-def fwd_geom(s: ConvSpec, B: int, IH: int, IW: int, ldi: int, ldo: int, es: int, x_coff: int = 0, y_coff: int = 0) -> ConvGeom:
+def fwd_geom(s: ConvSpec, B: int, IH: int, IW: int, ldi: int, ldo: int, es: int, x_coff: int = 0, y_coff: int = 0,
+             orig_hw=None) -> ConvGeom:
     OH, OW = out_size(IH, s), out_size(IW, s)
     if s.first:
-        cp = 16 // es
-        assert s.k <= 8 and ldi == cp
+        # x is the space-to-depth(2) image [B, IH, IW, 16]; OH/OW come from the ORIGINAL image size (orig_hw)
+        off0, taps = first_layer_taps(s)
+        assert ldi == S2D_CH and orig_hw is not None
+        OH, OW = out_size(orig_hw[0], s), out_size(orig_hw[1], s)
         return _geom(B=B, MH=OH, MW=OW, IH=IH, IW=IW, ldi=ldi, x_coff=0, OH=OH, OW=OW, ldo=ldo, y_coff=y_coff,
-                     oys=1, oy0=0, oxs=1, ox0=0, iys=s.stride, ixs=s.stride, ntaps=s.k, krun=8 * cp,
-                     pix_shift=int(math.log2(cp)), N=s.cout, dy=[kh - s.pad for kh in range(s.k)], dx=[-s.pad] * s.k)
+                     oys=1, oy0=0, oxs=1, ox0=0, iys=1, ixs=1, ntaps=taps, krun=4 * S2D_CH, pix_shift=4, N=s.cout,
+                     dy=[off0 + i for i in range(taps)], dx=[off0] * taps)
     assert (s.cin * es) % 64 == 0, f"Cin={s.cin} not a multiple of {64 // es}"
     taps = [(kh - s.pad, kw - s.pad) for kh in range(s.k) for kw in range(s.k)]
     return _geom(B=B, MH=OH, MW=OW, IH=IH, IW=IW, ldi=ldi, x_coff=x_coff, OH=OH, OW=OW, ldo=ldo, y_coff=y_coff,
@@ -96,12 +138,12 @@ def pack_fwd(w: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Tensor:
     """OIHW fp32 -> [npad][taps*krun] `dtype` (k contiguous)."""
     O = w.shape[0]
     npad = _L().am_conv_npad(O)
-    wt = w.detach().permute(0, 2, 3, 1)  # [O, kh, kw, I]
     if s.first:
-        cp = image_channels(dtype)
-        buf = w.new_zeros(O, s.k, 8, cp)
-        buf[:, :, : s.k, : s.cin] = wt
-        wt = buf
+        idx = _first_index(s, w.device)[0]
+        flat = torch.cat([w.detach().reshape(O, -1), w.new_zeros(O, 1)], dim=1)  # last column = structural zero
+        wt = flat[:, torch.where(idx < 0, torch.full_like(idx, flat.shape[1] - 1), idx)]
+    else:
+        wt = w.detach().permute(0, 2, 3, 1)  # [O, kh, kw, I]
     out = torch.zeros(npad, wt[0].numel(), dtype=dtype, device=w.device)
     out[:O] = wt.reshape(O, -1).to(dtype)
     return out
@@ -111,10 +153,11 @@ def unpack_wgrad(dwp: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Te
     """packed fp32 [O][taps*krun] -> OIHW fp32 gradient."""
     O = s.cout
     if s.first:
-        cp = image_channels(dtype)
-        g = dwp[:O].reshape(O, s.k, 8, cp)[:, :, : s.k, : s.cin]
-    else:
-        g = dwp[:O].reshape(O, s.k, s.k, s.cin)
+        _, pos, tgt = _first_index(s, dwp.device)  # packed positions that hold a weight, and where each one belongs
+        g = torch.zeros(O, s.cin * s.k * s.k, dtype=torch.float32, device=dwp.device)
+        g.index_copy_(1, tgt, dwp[:O].index_select(1, pos))  # every weight appears exactly once: no accumulation
+        return g.reshape(O, s.cin, s.k, s.k)
+    g = dwp[:O].reshape(O, s.k, s.k, s.cin)
     return g.permute(0, 3, 1, 2).contiguous()
 
 
@@ -226,11 +269,24 @@ def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp, k_real: Optional[int] = No
                                                            ptr(dwp), stream()))
 
 
+PENDING_BN_COUNTERS = []
+FUSE_FIRST_LAYER = True  # tests flip this to compare the fused first layer with the unfused sequence
+
+
+def flush_bn_counters():
+    """num_batches_tracked += 1 for every BatchNorm that ran in train mode since the last flush: one multi-tensor launch
+    instead of one tiny kernel per layer."""
+    if PENDING_BN_COUNTERS:
+        torch._foreach_add_(list(PENDING_BN_COUNTERS), 1)
+        PENDING_BN_COUNTERS.clear()
+
+
 class _Cfg:
     """Static description of one conv(+BN)(+ReLU) layer, shared by forward and backward."""
 
-    def __init__(self, spec: ConvSpec, cache: PackedWeights, bn=None, relu=False, loss_scale=1.0):
+    def __init__(self, spec: ConvSpec, cache: PackedWeights, bn=None, relu=False, loss_scale=1.0, orig_hw=None):
         self.spec, self.cache, self.bn, self.relu, self.loss_scale = spec, cache, bn, relu, loss_scale
+        self.orig_hw = orig_hw  # original image size when the input is the space-to-depth image (first layers)
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -244,11 +300,14 @@ class ConvBnAct(torch.autograd.Function):
         s, L = cfg.spec, _L()
         B, IH, IW, ldi = x.shape
         es = x.element_size()
-        OH, OW = out_size(IH, s), out_size(IW, s)
+        orig_hw = (cfg.orig_hw or getattr(x, "orig_hw", None)) if s.first else None
+        if s.first and orig_hw is None:
+            raise RuntimeError("first-layer conv expects the space-to-depth image from hip.ops.image_to_s2d()")
+        OH, OW = (out_size(orig_hw[0], s), out_size(orig_hw[1], s)) if s.first else (out_size(IH, s), out_size(IW, s))
         dtype, dev = x.dtype, x.device
         cout = s.cout
         ldo = channel_ld(cout, es)
-        g = fwd_geom(s, B, IH, IW, ldi, ldo, es)
+        g = fwd_geom(s, B, IH, IW, ldi, ldo, es, orig_hw=orig_hw)
         wp = cfg.cache.get_fwd(w, s, dtype)
         bn = cfg.bn
         alloc = torch.zeros if ldo != cout else torch.empty
@@ -259,8 +318,23 @@ class ConvBnAct(torch.autograd.Function):
             y, mean, rstd = raw, None, None
         else:
             use_batch = training or bn.running_mean is None
-            stats = torch.zeros(AM_STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=dev) if use_batch else None
-            conv_gemm(g, x, wp, b, False, raw, stats, k_real=s.cin * s.k * s.k)
+            stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev) if use_batch else None
+            # Frozen first layer in train-mode BN (AutoMoE's gating stage): two light passes over the image instead of
+            # conv -> raw output -> normalise pass.  Only when nothing here needs a gradient (raw output is not kept).
+            fused_first = (s.first and use_batch and b is None and residual is None and cfg.relu and dtype == torch.float16
+                           and not (w.requires_grad or gamma.requires_grad or beta.requires_grad) and FUSE_FIRST_LAYER)
+            if fused_first:
+                import ctypes
+                try:
+                    # statistics pass: a recompute, so it adds time but no algorithmic FLOPs to the roofline accounting
+                    _timed("conv_gemm", 0.0,
+                           lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 1, ptr(x), ptr(wp), None, None, None, ptr(stats), stream()))
+                except RuntimeError as e:
+                    if "UNSUPPORTED" not in str(e):
+                        raise
+                    fused_first = False
+            if not fused_first:
+                conv_gemm(g, x, wp, b, False, raw, stats, k_real=s.cin * s.k * s.k)
             scale = torch.empty(cout, dtype=torch.float32, device=dev)
             shift = torch.empty_like(scale)
             mean = torch.empty_like(scale)
@@ -272,7 +346,12 @@ class ConvBnAct(torch.autograd.Function):
                              ptr(bn.running_var) if (upd or not use_batch) else None, float(momentum), float(bn.eps),
                              int(use_batch), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), cout, stream())
             if upd and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # bumped together by flush_bn_counters()
+            if fused_first:
+                import ctypes
+                _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * cout,
+                       lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 2, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(raw), None, stream()))
+                return raw  # no graph: nothing requires grad
             y = torch.empty_like(raw)
             L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
                           residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
@@ -297,7 +376,7 @@ class ConvBnAct(torch.autograd.Function):
         code = dt_code(dtype)
         db = dgamma = dbeta = dres = None
         if cfg.bn is not None:
-            sums = torch.zeros(AM_STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=dev)
+            sums = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev)
             L.am_bn_bwd_reduce(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), int(cfg.relu), ptr(sums), P,
                                cout, stream())
             coef = torch.empty(3 * cout, dtype=torch.float32, device=dev)
@@ -344,6 +423,8 @@ class ConvBnAct(torch.autograd.Function):
 
 
 def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
+    if cfg.spec.first and cfg.orig_hw is None:
+        cfg.orig_hw = getattr(x, "orig_hw", None)
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     return ConvBnAct.apply(x, w, b, gamma, beta, residual, cfg, training)

@@ -22,21 +22,29 @@ def _L():
 # --------------------------------------------------------------------------------------------
 # boundary layout
 # --------------------------------------------------------------------------------------------
-def image_to_nhwc(img: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[B,3,H,W] fp32 NCHW (the reference's batch['image']) -> [B,H,W,16 B/pixel] NHWC `dtype`.  No gradient:
-    the image is never a leaf that requires grad on this path."""
+def image_to_s2d(img: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[B,3,H,W] fp32 NCHW (the reference's batch['image']) -> space-to-depth(2) NHWC [B,ceil(H/2),ceil(W/2),16] `dtype`
+    (channel (py*2+px)*3 + c = img[b,c,2Y+py,2X+px]); the 3-channel stride-2 first layers run on it as stride-1 convs with
+    16 input channels.  The original size rides along as `.orig_hw`.  No gradient: the image is never a leaf that requires
+    grad on this path.  Odd sizes are zero-padded by one row/column, which the convs' own zero padding makes exact."""
     require_hip(img, "image")
     img = img.detach()
     if img.dtype != torch.float32:
         img = img.float()
-    img = img.contiguous()
     B, C, H, W = img.shape
-    ld = 16 // torch.empty((), dtype=dtype).element_size()
-    if C > ld:
-        raise ValueError(f"image has {C} channels; the first-layer kernel handles at most {ld}")
-    out = torch.empty((B, H, W, ld), dtype=dtype, device=img.device)
-    _L().am_nchw_to_nhwc(dt_code(dtype), ptr(img), ptr(out), B, C, H, W, ld, 1.0, stream())
+    if C > 4:
+        raise ValueError(f"image has {C} channels; the first-layer path handles at most 4")
+    if (H & 1) or (W & 1):
+        img = torch.nn.functional.pad(img, (0, W & 1, 0, H & 1))
+    img = img.contiguous()
+    H2, W2 = img.shape[2] // 2, img.shape[3] // 2
+    out = torch.empty((B, H2, W2, 16), dtype=dtype, device=img.device)
+    _L().am_image_s2d(dt_code(dtype), ptr(img), ptr(out), B, C, img.shape[2], img.shape[3], stream())
+    out.orig_hw = (H, W)
     return out
+
+
+image_to_nhwc = image_to_s2d  # the boundary layout every backbone entry point expects
 
 
 class NhwcToNchw(torch.autograd.Function):
@@ -289,7 +297,8 @@ class DropoutFn(torch.autograd.Function):
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         _DROPOUT_CALLS += 1
         seed = (torch.initial_seed() * 0x9E3779B1 + _DROPOUT_CALLS * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
-        _L().am_dropout_fwd(ptr(x), ptr(y), ptr(mask), x.numel(), float(p), seed, stream())
+        from .. import runtime
+        _L().am_dropout_fwd(ptr(x), ptr(y), ptr(mask), x.numel(), float(p), seed, ptr(runtime.step_counter(x.device)), stream())
         ctx.p = p
         ctx.save_for_backward(mask)
         return y

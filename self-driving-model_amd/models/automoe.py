@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import runtime
+from ..hip import conv as hconv
 from ..hip import ops as hops
 from .context.context_features import create_context_extractor
 from .experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
@@ -131,6 +132,7 @@ class AutoMoE(nn.Module):
         return outs, feats
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        runtime.begin_step(batch["image"].device)
         context_features = self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
         if self.fuse_expert_pooling:
@@ -140,6 +142,7 @@ class AutoMoE(nn.Module):
             expert_features = self.expert_extractors.extract_features(expert_outputs)
         gating_output = self.gating_network(expert_features, context_features)
         policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc)
+        hconv.flush_bn_counters()
         speed_seq = policy_output.get("speed")
         speed_out = speed_seq[:, -1:].contiguous() if speed_seq is not None and speed_seq.dim() == 2 else None
         return {

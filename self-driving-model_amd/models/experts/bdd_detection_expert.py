@@ -2,6 +2,7 @@
 import torch.nn as nn
 
 from ... import runtime
+from ...hip import conv as hconv
 from ...hip import ops as hops
 from .._nn import Conv2d, conv_bn_act
 from .resnet import Trunk, load_pretrained_
@@ -22,8 +23,12 @@ class BDDDetectionExpert(nn.Module):
 
     def forward(self, x, nhwc_input=None):
         """x: [B,3,H,W] fp32 NCHW.  Returns NCHW fp32 channel slices, as the reference."""
+        if nhwc_input is None:
+            runtime.begin_step(x.device)
         xin = nhwc_input if nhwc_input is not None else hops.image_to_nhwc(x, runtime.compute_dtype())
         out = hops.NhwcToNchw.apply(self.features_nhwc(xin), self.num_classes + 4, runtime.loss_scale())
+        if nhwc_input is None:
+            hconv.flush_bn_counters()
         return {"class_logits": out[:, : self.num_classes, :, :], "bbox_deltas": out[:, self.num_classes:, :, :]}
 
     def predict(self, x):

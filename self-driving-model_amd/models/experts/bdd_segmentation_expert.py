@@ -2,6 +2,7 @@
 import torch.nn as nn
 
 from ... import runtime
+from ...hip import conv as hconv
 from ...hip import ops as hops
 from .._nn import Conv2d, conv_bn_act
 from .resnet import Trunk, load_pretrained_
@@ -30,8 +31,12 @@ class _DenseExpert(nn.Module):
         return hops.UpsampleGap.apply(low, self.num_classes, x.shape[-2], x.shape[-1], runtime.loss_scale()), low
 
     def forward(self, x, nhwc_input=None):
+        if nhwc_input is None:
+            runtime.begin_step(x.device)
         xin = nhwc_input if nhwc_input is not None else hops.image_to_nhwc(x, runtime.compute_dtype())
         low = self.lowres_nhwc(xin)
+        if nhwc_input is None:
+            hconv.flush_bn_counters()
         return hops.BilinearUp.apply(low, self.num_classes, x.shape[-2], x.shape[-1], runtime.loss_scale())
 
 

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from ... import runtime
+from ...hip import conv as hconv
 from ...hip import ops as hops
 from .._nn import BatchNorm2d, Conv2d, Linear, MLPSequential, ReLU, conv_bn_act
 
@@ -24,9 +25,13 @@ class EasyBackbone(nn.Module):
         self.fc = Linear(256, out_dim)
 
     def forward(self, x: torch.Tensor, nhwc_input: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if nhwc_input is None:
+            runtime.begin_step(x.device)
         h = nhwc_input if nhwc_input is not None else hops.image_to_nhwc(x, runtime.compute_dtype())
         for i in range(0, 12, 3):
             h = conv_bn_act(h, self.net[i], self.net[i + 1], relu=True)
+        if nhwc_input is None:
+            hconv.flush_bn_counters()
         return self.fc(hops.GapNhwc.apply(h, runtime.loss_scale()))
 
 

@@ -54,3 +54,43 @@ def precision(dtype: torch.dtype, loss_scale: float | None = None):
         yield
     finally:
         _STATE.update({"dtype": old["dtype"], "loss_scale": old["loss_scale"]})
+
+
+# ---- per-step zeroed fp64 arena for BatchNorm statistics ---------------------------------------------------------
+# Every conv+BN layer needs a small zeroed fp64 accumulator (forward sums, backward sums).  Allocating and zero-filling
+# ~130 of them per step costs more launches than the arithmetic; instead one buffer is zeroed by a single memset at
+# begin_step() and handed out in slices.  A slice is only valid until the next begin_step().
+_ARENA = {"buf": None, "off": 0, "cap": 1 << 22}
+
+
+_STEP = {"counter": None}
+
+
+def step_counter(device) -> torch.Tensor:
+    """Device int64 incremented by begin_step(): kernels that need per-step randomness (dropout) read it on the device,
+    which keeps them correct under hipGraph replay where host-side counters are frozen."""
+    if _STEP["counter"] is None or _STEP["counter"].device != torch.device(device):
+        _STEP["counter"] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _STEP["counter"]
+
+
+def begin_step(device=None):
+    """Zero the statistics arena (one memset) and bump the device step counter.  Called at the start of every model
+    forward / train step."""
+    a = _ARENA
+    if device is not None:
+        step_counter(device).add_(1)
+    if a["buf"] is None or (device is not None and a["buf"].device != torch.device(device)):
+        a["buf"] = torch.zeros(a["cap"], dtype=torch.float64, device=device if device is not None else "cuda")
+    else:
+        a["buf"].zero_()
+    a["off"] = 0
+
+
+def arena_zeros(n: int, device) -> torch.Tensor:
+    a = _ARENA
+    if a["buf"] is None or a["buf"].device != torch.device(device) or a["off"] + n > a["cap"]:
+        return torch.zeros(n, dtype=torch.float64, device=device)  # outside a step (or exhausted): plain allocation
+    out = a["buf"][a["off"]:a["off"] + n]
+    a["off"] += (n + 1) & ~1
+    return out

@@ -27,6 +27,7 @@ class GradBucketReducer:
         self.buckets = []  # (start, end, n_params)
         self._bucket_of = {}
         self._pending, self._handles = [], []
+        self.paused = False  # True while a hipGraph owns backward: hooks stay silent, reduce_all() runs after the replay
         self.side = torch.cuda.Stream() if flat_grad.is_cuda else None
         if not self.enabled:
             return
@@ -63,6 +64,8 @@ class GradBucketReducer:
 
     def _make_hook(self, idx):
         def hook(_param):
+            if self.paused:
+                return
             b = self._bucket_of[idx]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -80,6 +83,12 @@ class GradBucketReducer:
                 self._handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self._handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def reduce_all(self):
+        """One all-reduce over the whole flat gradient buffer (used after a graph replay, where per-bucket hooks did not run)."""
+        if not self.enabled:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self):
         """Block the compute stream until every bucket is reduced; buckets whose hooks never fired (unused

@@ -63,9 +63,15 @@ def compute_gating_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor
 
 class GatingTrainStep:
     """One optimisation step of the gating stage: zero_grad -> forward -> losses -> backward (+ overlapped
-    all-reduce) -> clip 1.0 + AdamW.  Holds the optimizer / reducer pair so callers (trainer, bench) share it."""
+    all-reduce) -> clip 1.0 + AdamW.  Holds the optimizer / reducer pair so callers (trainer, bench) share it.
 
-    def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = 25):
+    With `use_graph` (default: env AUTOMOE_HIPGRAPH, on) the launch-bound part of the step -- zero_grad, forward,
+    losses, backward: ~900 small launches -- is captured once into a hipGraph (torch.cuda.CUDAGraph over our kernels,
+    which run on the capturing stream) and replayed; the gradient exchange and the fused optimizer stay outside the
+    graph so the learning rate / step count remain host-driven.  Under a graph the gradient all-reduce is issued as one
+    collective after the replay instead of per bucket from hooks (11.5 MB in the reference's frozen-expert stage)."""
+
+    def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = 25, use_graph=None):
         self.model = model
         self.core = model.module if hasattr(model, "module") else model
         self.config = config
@@ -77,13 +83,54 @@ class GatingTrainStep:
         self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
                                          bucket_bytes=bucket_mb << 20, broadcast_from=self.optimizer.flat_p)
         self.optimizer.grad_divisor = float(self.reducer.world)
+        if use_graph is None:
+            use_graph = os.environ.get("AUTOMOE_HIPGRAPH", "1") != "0"
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._static_batch = None
+        self._static_losses = None
+        self._eager_steps = 0
 
-    def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
         pred = self.model(batch)
         losses = compute_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
         losses["total_loss"].backward()
-        self.reducer.finish()
+        return losses
+
+    def _capture(self, batch):
+        self._static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        self.reducer.paused = True  # hooks must not launch collectives inside the capture
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                losses = self._fwd_bwd(self._static_batch)
+            self._graph, self._static_losses = g, losses
+        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
+            import traceback
+            import warnings
+            warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing without a graph\n"
+                          + "".join(traceback.format_exc().splitlines(True)[-14:]))
+            self.use_graph = False
+            self._graph = None
+            torch.cuda.synchronize()
+        finally:
+            self.reducer.paused = self._graph is not None
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:
+            self._capture(batch)
+        if self._graph is not None:
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
+                    self._static_batch[k].copy_(v, non_blocking=True)
+            self._graph.replay()
+            losses = self._static_losses
+            self.reducer.reduce_all()
+        else:
+            losses = self._fwd_bwd(batch)
+            self.reducer.finish()
+            self._eager_steps += 1
         self.optimizer.step()
         return losses
 

@@ -143,6 +143,7 @@ def test_conv_bn_relu_train_vs_torch(dtype, with_res, conv_bias):
         close(nchw(y, cout), yr, what="y")
         close(bn_hip.running_mean, bn_ref.running_mean, what="running_mean")
         close(bn_hip.running_var, bn_ref.running_var, what="running_var")
+        hc.flush_bn_counters()
         assert int(bn_hip.num_batches_tracked) == 1
         close(nchw(xd.grad, cin), xr.grad, rtol=RT, atol=1e-4, what="dx")
         close(wd.grad, wr.grad, rtol=RT, atol=2e-4, what="dw")
@@ -397,3 +398,57 @@ def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
     st = stats.view(16, 2, 64).sum(0).cpu()
     np.testing.assert_allclose(st[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=0.5)
     np.testing.assert_allclose(st[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("spec", [(64, 7, 3), (32, 5, 2)])
+def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
+    """Large first-layer problems run the weights-stationary s2d kernel (conv_s2d.hip).  Mode 0 (raw + statistics) is
+    checked against torch; the frozen-stem two-pass path (statistics-only pass, then conv+BN+ReLU in the epilogue) must
+    equal the unfused sequence conv -> BatchNorm2d(train) -> ReLU, including the running-statistics update."""
+    import torch.nn as nn
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    cout, k, pad = spec
+    B, H, W = 2, 390, 518  # odd halves exercise ragged edge tiles: out 195 x 259
+    g = torch.Generator().manual_seed(k)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(cout, 3, k, k, generator=g) / (3 * k * k) ** 0.5
+    bn_ref = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * torch.randn(cout, generator=g))
+        bn_ref.bias.copy_(0.2 * torch.randn(cout, generator=g))
+    yr_raw = F.conv2d(img.half().float(), w.half().float(), stride=2, padding=pad)
+    yr = F.relu(bn_ref(yr_raw))
+    s = hc.ConvSpec(3, cout, k, 2, pad, first=True)
+    outs = {}
+    for fused in (False, True):
+        hc.FUSE_FIRST_LAYER = fused
+        bn = nn.BatchNorm2d(cout)
+        bn.load_state_dict({k2: v.clone() for k2, v in nn.BatchNorm2d(cout).state_dict().items()})
+        with torch.no_grad():
+            bn.weight.copy_(bn_ref.weight); bn.bias.copy_(bn_ref.bias)
+        bn.to(_dev()).train()
+        for p_ in bn.parameters():
+            p_.requires_grad = False
+        wd = w.to(_dev())
+        with runtime.precision(torch.float16, 1.0):
+            x = hops.image_to_s2d(img.to(_dev()), torch.float16)
+            cfg = hc._Cfg(s, hc.PackedWeights(), bn, True, 1.0)
+            y = hc.conv_bn_act(x, wd, None, bn, True, None, cfg, True)
+        hc.flush_bn_counters()
+        outs[fused] = (y, bn)
+    hc.FUSE_FIRST_LAYER = True
+    for fused in (False, True):
+        y, bn = outs[fused]
+        assert rel_err(nchw(y, cout), yr) < 3e-3, fused
+        close(bn.running_mean, bn_ref.running_mean, rtol=2e-3, atol=2e-4)
+        close(bn.running_var, bn_ref.running_var, rtol=2e-3, atol=2e-4)
+        assert int(bn.num_batches_tracked) == 1
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    # mode 0 alone: raw conv output and its statistics
+    with runtime.precision(torch.float16, 1.0):
+        x = hops.image_to_s2d(img.to(_dev()), torch.float16)
+        cfg = hc._Cfg(s, hc.PackedWeights(), None, False, 1.0)
+        raw = hc.conv_bn_act(x, w.to(_dev()), None, None, False, None, cfg, False)
+    assert rel_err(nchw(raw, cout), yr_raw) < 2e-3

@@ -399,3 +399,37 @@ def test_fused_upsample_pool_matches_unfused_and_oracle():
     for n in ("experts.1.decoder.2.weight", "experts.2.decoder.0.weight", "expert_extractors.extractors.1.feature_extractor.2.weight",
               "experts.1.backbone.7.1.conv2.weight"):
         close(g_f[n], g_u[n], rtol=2e-3, atol=1e-5, what=n)
+
+
+def test_train_step_hipgraph_matches_eager():
+    """GatingTrainStep with the forward/backward captured in a hipGraph must walk the same parameter trajectory as the
+    eager step (dropout off so both are deterministic up to fp32 atomics order)."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+    from oracle import torch_ref as oref
+    ref = seed_module_(oref.create_automoe_model(AUTOMOE_CFG, "cpu"), 90)
+    batch = {k: v.to(_dev()) for k, v in _batch(2, 64, 96, 91).items()}
+    finals = {}
+    with runtime.precision(torch.float32):
+        for use_graph in (False, True):
+            m = create_automoe_model(AUTOMOE_CFG, "cpu")
+            m.load_state_dict(ref.state_dict())
+            m.to(_dev())
+            m.freeze_experts()
+            m.train()
+            for d in m.modules():
+                if isinstance(d, torch.nn.Dropout):
+                    d.p = 0.0
+            step = GatingTrainStep(m, {"learning_rate": 1e-3, "weight_decay": 1e-4}, use_graph=use_graph)
+            losses = [float(step(batch)["total_loss"]) for _ in range(6)]
+            assert (step._graph is not None) == use_graph
+            finals[use_graph] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    le, lg = finals[False][0], finals[True][0]
+    assert le[-1] < le[0]  # it trains
+    np.testing.assert_allclose(lg, le, rtol=2e-3, atol=1e-4)
+    for k, v in finals[False][1].items():
+        if v.dtype.is_floating_point:
+            close(finals[True][1][k], v, rtol=5e-3, atol=5e-4, what=k)
+        else:
+            assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked advanced identically

@@ -62,13 +62,33 @@ def test_geometry_and_packing(lib):
     # 1x1 stride-2 projection: only the even/even class has a tap, the other three write zeros
     plans = hc.dgrad_plans(hc.ConvSpec(64, 128, 1, 2, 0), 1, 46, 80, 64, 128, 2)
     assert [len(t) for _, t in plans] == [1, 0, 0, 0]
+    # 3-channel stride-2 first layers run on the space-to-depth(2) image: 7x7/p3 -> 4x4 taps, 5x5/p2 -> 3x3 taps
     first = hc.ConvSpec(3, 64, 7, 2, 3, first=True)
-    gf = hc.fwd_geom(first, 1, 720, 1280, 8, 64, 2)
-    assert (gf.MH, gf.MW, gf.ntaps, gf.krun, gf.pix_shift) == (360, 640, 7, 64, 3) and list(gf.dx)[:7] == [-3] * 7
-    w = torch.arange(64 * 3 * 7 * 7, dtype=torch.float32).reshape(64, 3, 7, 7)
+    assert hc.first_layer_taps(first) == (-2, 4) and hc.first_layer_taps(hc.ConvSpec(3, 32, 5, 2, 2, first=True)) == (-1, 3)
+    gf = hc.fwd_geom(first, 1, 360, 640, 16, 64, 2, orig_hw=(720, 1280))
+    assert (gf.MH, gf.MW, gf.IH, gf.IW, gf.ntaps, gf.krun, gf.pix_shift) == (360, 640, 360, 640, 4, 64, 4)
+    assert list(gf.dy)[:4] == [-2, -1, 0, 1] and list(gf.dx)[:4] == [-2] * 4
+    w = torch.arange(64 * 3 * 7 * 7, dtype=torch.float32).reshape(64, 3, 7, 7) + 1
     wp = hc.pack_fwd(w, first, torch.float32)
-    assert wp.shape == (64, 7 * 8 * 4)
+    assert wp.shape == (64, 4 * 4 * 16) and int((wp != 0).sum()) == 64 * 147   # every weight lands exactly once
     assert torch.equal(hc.unpack_wgrad(wp, first, torch.float32), w)                      # pack/unpack are inverse
+    p5 = hc.ConvSpec(3, 32, 5, 2, 2, first=True)
+    w5 = torch.randn(32, 3, 5, 5)
+    wp5 = hc.pack_fwd(w5, p5, torch.float32)
+    assert wp5.shape == (32, 3 * 4 * 16) and torch.equal(hc.unpack_wgrad(wp5, p5, torch.float32), w5)
+    # space-to-depth conv == the original conv (CPU check of the index algebra)
+    img = torch.randn(2, 3, 20, 28)
+    ref = torch.nn.functional.conv2d(img, w5, stride=2, padding=2)
+    s2d = img.reshape(2, 3, 10, 2, 14, 2).permute(0, 2, 4, 3, 5, 1).reshape(2, 10, 14, 12)
+    s2d = torch.nn.functional.pad(s2d, (0, 4))
+    off0, taps = hc.first_layer_taps(p5)
+    pad = torch.nn.functional.pad(s2d, (0, 0, -off0, 4, -off0, 4))
+    wk = wp5.reshape(32, taps, 4, 16)
+    out = torch.zeros(2, 10, 14, 32)
+    for i in range(taps):
+        for j in range(4):
+            out += torch.einsum("byxc,nc->byxn", pad[:, i:i + 10, j:j + 14, :], wk[:, i, j, :])
+    assert torch.allclose(out.permute(0, 3, 1, 2), ref, atol=1e-4)
     w3 = torch.randn(128, 64, 3, 3)
     assert torch.equal(hc.unpack_wgrad(hc.pack_fwd(w3, s, torch.float32), s, torch.float32), w3)
     assert hc.channel_ld(14, 2) == 32 and hc.channel_ld(19, 4) == 32 and hc.channel_ld(3, 4) == 16 and hc.channel_ld(256, 2) == 256
