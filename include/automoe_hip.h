@@ -81,7 +81,8 @@ int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w,
 /* Fused first layer for frozen (no-gradient) stems in train-mode BatchNorm, f16, space-to-depth geometry only
  * (conv -> BatchNorm2d(batch statistics) -> ReLU of bdd_*_expert.py:9-11 without writing the raw conv output):
  *   mode 1: accumulate the BatchNorm statistics of the conv output into `stats`, write nothing;
- *   mode 2: y = relu(conv * scale[n] + shift[n]) with scale/shift from am_bn_finalize.
+ *   mode 2: y = relu(conv * scale[n] + shift[n]) with scale/shift from am_bn_finalize;
+ *   mode 3: y = MaxPool2d(3,2,1)(relu(conv * scale[n] + shift[n])), y = [B,(OH-1)/2+1,(OW-1)/2+1,ldo] (ResNet stem + maxpool).
  * Returns AM_ERR_UNSUPPORTED when the geometry / size is not covered (caller uses am_conv_gemm + am_bn_apply). */
 int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
                         const float* shift, void* y, double* stats, am_stream_t stream);

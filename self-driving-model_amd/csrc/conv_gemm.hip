@@ -568,6 +568,6 @@ extern "C" int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, c
   int rc = check_geom(g, dtype);
   if (rc != AM_OK) return rc;
   if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
-  if (!x || !w || (mode == 1 && !stats) || (mode == 2 && (!y || !scale || !shift)) || (mode != 1 && mode != 2)) return AM_ERR_ARG;
+  if (!x || !w || (mode == 1 && !stats) || ((mode == 2 || mode == 3) && (!y || !scale || !shift)) || mode < 1 || mode > 3) return AM_ERR_ARG;
   return am_conv_s2d_f16(g, mode, x, w, nullptr, scale, shift, 1, y, stats, static_cast<hipStream_t>(stream));
 }

@@ -11,6 +11,7 @@
 //   0  raw conv output (+bias) and BatchNorm statistics           -- drop-in for the gather-GEMM
 //   1  BatchNorm statistics only, nothing written                  -- pass 1 of the fused stem
 //   2  y = relu(conv * scale[n] + shift[n])                        -- pass 2: BN(train) + ReLU applied in the epilogue
+//   3  y = maxpool3x3s2(relu(conv * scale[n] + shift[n]))          -- pass 2 of the ResNet stem: only the pooled map is written
 // Pass 1 + pass 2 recompute the (cheap) conv instead of writing the raw output, reading it back for the normalise
 // pass and writing it again: 0.47 GB instead of 3.3 GB of HBM traffic per 32 images for the ResNet stem.
 #include "am_common.h"
@@ -242,6 +243,181 @@ int launch_s2d(const S2dParams& p, hipStream_t s) {
   return AM_OK;
 }
 
+// ---- mode 3: conv -> BN(scale, shift) -> ReLU -> MaxPool2d(3, 2, 1), nothing but the pooled map is written ----------
+// 8 waves, conv tile 16 x 32 (wave w: rows 2w, 2w+1) = the 15 x 31 conv outputs behind a 7 x 15 pooled tile (+1 spare
+// row / column); neighbouring tiles recompute the one-pixel overlap (27 % extra MFMA work on a layer that is far from
+// MFMA-bound) instead of exchanging halos.  Post-ReLU values are >= 0 and every pooling window holds at least one
+// in-image conv output, so out-of-image positions are staged as 0 (equivalent to max-pool's -inf padding).
+constexpr int PTH = 7, PTW = 15, CTH = 16, CTW = 32;
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int POH, int POW, int ptiles_y, int ptiles_x) {
+  constexpr int NT = 2, NCH = 64;
+  constexpr int PH = CTH + TAPS - 1, PW = CTW + TAPS - 1;
+  constexpr int PATCH_BYTES = PH * PW * CB;
+  constexpr int PATCH_INST = (PATCH_BYTES + 1023) / 1024;
+  constexpr int PATCH_SLOT = PATCH_INST * 1024;
+  constexpr int KSTEPS = TAPS * TAPS;
+  constexpr int WPITCH = KSTEPS * 32 + 16;
+  constexpr int WCH = WPITCH / 16;
+  constexpr int W_BYTES = ((NCH * WPITCH + 1023) / 1024) * 1024;
+  constexpr int SPX = NCH * 2;  // staging: [16 rows][32 px][64 ch] halves, 128 B per pixel
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* Wl = smem;
+  char* patch0 = smem + W_BYTES;
+  char* stg = smem + W_BYTES + 2 * PATCH_SLOT;
+
+  const char* __restrict__ x = static_cast<const char*>(p.x);
+  const char* __restrict__ w = static_cast<const char*>(p.w);
+  half_t* __restrict__ y = static_cast<half_t*>(p.y);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const char* zl = reinterpret_cast<const char*>(g_zero_line);
+  const int ktot_bytes = TAPS * 64 * 2;
+
+  for (int inst = wid; inst < W_BYTES / 1024; inst += 8) {
+    const int q = inst * 64 + lane;
+    const int n = q / WCH, cc = q - n * WCH;
+    const char* src = zl;
+    if (n < NCH && cc < KSTEPS * 2) {
+      const int tap = cc >> 1, i = tap / TAPS, j = tap - i * TAPS;
+      src = w + (long long)n * ktot_bytes + ((i * 4 + j) * 16) * 2 + (cc & 1) * 16;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(Wl + inst * 1024), 16, 0, 0);
+  }
+
+  auto tile_origin = [&](int tile, int& img, int& pty, int& ptx) {
+    img = tile / (ptiles_y * ptiles_x);
+    const int rem = tile - img * (ptiles_y * ptiles_x);
+    pty = rem / ptiles_x;
+    ptx = rem - pty * ptiles_x;
+  };
+  auto issue_patch = [&](int tile, int buf) {
+    int img, pty, ptx;
+    tile_origin(tile, img, pty, ptx);
+    const int iy0 = 2 * PTH * pty - 1 + p.off0, ix0 = 2 * PTW * ptx - 1 + p.off0;
+    char* dst = patch0 + buf * PATCH_SLOT;
+    for (int inst = wid; inst < PATCH_INST; inst += 8) {
+      const int q = inst * 64 + lane;
+      const int pidx = q >> 1, cpos = q & 1;
+      const int c = cpos ^ ((pidx >> 3) & 1);
+      const int prow = pidx / PW, pcol = pidx - prow * PW;
+      const int iy = iy0 + prow, ix = ix0 + pcol;
+      const bool ok = q < PATCH_BYTES / 16 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const char* src = ok ? x + ((long long)(img * p.IH + iy) * p.IW + ix) * CB + c * 16 : zl;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) issue_patch(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float sc[NT], sh[NT];
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    sc[tn] = p.scale[tn * 32 + (lane & 31)];
+    sh[tn] = p.shift[tn * 32 + (lane & 31)];
+  }
+  const int rx = lane & 31, kg = lane >> 5;
+  int buf = 0;
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) issue_patch(next, buf ^ 1);
+    const char* pt = patch0 + buf * PATCH_SLOT;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) {
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        const int pid0 = (2 * wid + i) * PW + rx + j;
+        const int pid1 = pid0 + PW;
+        const half8_t fa0 = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((kg ^ ((pid0 >> 3) & 1)) << 4));
+        const half8_t fa1 = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((kg ^ ((pid1 >> 3) & 1)) << 4));
+        const char* bb = Wl + (lane & 31) * WPITCH + (i * TAPS + j) * 32 + kg * 16;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          const half8_t fb = *reinterpret_cast<const half8_t*>(bb + tn * 32 * WPITCH);
+          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb, acc[0][tn], 0, 0, 0);
+          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb, acc[1][tn], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // next patch landed; every wave is done with this patch AND with the previous tile's staging reads
+    buf ^= 1;
+
+    int img, pty, ptx;
+    tile_origin(tile, img, pty, ptx);
+    const int cy0 = 2 * PTH * pty - 1, cx0 = 2 * PTW * ptx - 1;  // conv-output coordinates of tile row/col 0
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int ry = 2 * wid + tm;
+      const bool rowok = (unsigned)(cy0 + ry) < (unsigned)p.OH;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * kg;
+          float v = fmaxf(acc[tm][tn][r] * sc[tn] + sh[tn], 0.f);
+          if (!(rowok && (unsigned)(cx0 + px) < (unsigned)p.OW)) v = 0.f;
+          *reinterpret_cast<half_t*>(stg + (ry * CTW + px) * SPX + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
+        }
+    }
+    __syncthreads();
+    // pooled tile: PTH x PTW pixels x 8 chunks of 8 channels; pooled (ppy, ppx) <- conv tile rows 2ppy..2ppy+2, cols 2ppx..2ppx+2
+    for (int e = tid; e < PTH * PTW * 8; e += 512) {
+      const int c8 = e & 7, pp = e >> 3;
+      const int ppy = pp / PTW, ppx = pp - ppy * PTW;
+      const int oy = pty * PTH + ppy, ox = ptx * PTW + ppx;
+      if (oy >= POH || ox >= POW) continue;
+      half8_t m = *reinterpret_cast<const half8_t*>(stg + ((2 * ppy) * CTW + 2 * ppx) * SPX + c8 * 16);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          if (dy == 0 && dx == 0) continue;
+          const half8_t t = *reinterpret_cast<const half8_t*>(stg + ((2 * ppy + dy) * CTW + 2 * ppx + dx) * SPX + c8 * 16);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) m[k] = t[k] > m[k] ? t[k] : m[k];
+        }
+      *reinterpret_cast<half8_t*>(y + ((long long)(img * POH + oy) * POW + ox) * p.ldo + p.y_coff + c8 * 8) = m;
+    }
+    // the barrier after the next tile's MFMA phase orders these staging reads before the next staging writes
+  }
+}
+
+template <int TAPS>
+int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
+  constexpr int PH = CTH + TAPS - 1, PW = CTW + TAPS - 1;
+  constexpr int PATCH_SLOT = ((PH * PW * CB + 1023) / 1024) * 1024;
+  constexpr int WPITCH = TAPS * TAPS * 32 + 16;
+  constexpr int W_BYTES = ((64 * WPITCH + 1023) / 1024) * 1024;
+  constexpr int LDS = W_BYTES + 2 * PATCH_SLOT + CTH * CTW * 128;
+  S2dParams p = p0;
+  const int pty = am_cdiv(POH, PTH), ptx = am_cdiv(POW, PTW);
+  p.ntiles = p.B * pty * ptx;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_pool_k<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int grid = p.ntiles < 256 ? p.ntiles : 256;
+  hipLaunchKernelGGL((conv_s2d_pool_k<TAPS>), dim3(grid), dim3(512), LDS, s, p, POH, POW, pty, ptx);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
 template <int MODE>
 int dispatch_s2d(const S2dParams& p, int taps, hipStream_t s) {
   if (taps == 4 && p.N > 32 && p.N <= 64) return launch_s2d<4, 2, MODE>(p, s);
@@ -272,6 +448,11 @@ int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* 
   p.tiles_y = am_cdiv(g->OH, TH);
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
+  if (mode == 3) {
+    // y is the max-pooled map [B, POH, POW, ldo], POH = (OH-1)/2+1
+    if (g->ntaps != 4 || g->N != 64) return AM_ERR_UNSUPPORTED;
+    return launch_s2d_pool<4>(p, (g->OH - 1) / 2 + 1, (g->OW - 1) / 2 + 1, s);
+  }
   if (mode == 0) return dispatch_s2d<0>(p, g->ntaps, s);
   if (mode == 1) return dispatch_s2d<1>(p, g->ntaps, s);
   if (mode == 2) return dispatch_s2d<2>(p, g->ntaps, s);

@@ -428,3 +428,51 @@ def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     return ConvBnAct.apply(x, w, b, gamma, beta, residual, cfg, training)
+
+
+@torch.no_grad()
+def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
+    """ResNet stem for a FROZEN trunk in train-mode BatchNorm: conv7x7/s2 -> BN(batch statistics, running stats
+    updated) -> ReLU -> MaxPool(3,2,1) as two passes over the space-to-depth image -- a statistics-only pass and a pass
+    whose epilogue normalises, rectifies and pools -- so neither the raw conv output nor the normalised map ever reaches
+    HBM.  Returns the pooled NHWC activation, or None when the case is not covered (caller runs the unfused sequence)."""
+    import ctypes
+    s = cfg.spec
+    if not (FUSE_FIRST_LAYER and s.first and x.dtype == torch.float16 and bn is not None and bn.training and s.cout == 64):
+        return None
+    if conv_w.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad:
+        return None
+    orig_hw = cfg.orig_hw or getattr(x, "orig_hw", None)
+    if orig_hw is None:
+        return None
+    L = _L()
+    B, IH, IW, ldi = x.shape
+    g = fwd_geom(s, B, IH, IW, ldi, 64, 2, orig_hw=orig_hw)
+    if g.ntaps != 4:
+        return None
+    OH, OW = g.OH, g.OW
+    P = B * OH * OW
+    dev = x.device
+    wp = cfg.cache.get_fwd(conv_w, s, x.dtype)
+    stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
+    try:
+        _timed("conv_gemm", 0.0, lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 1, ptr(x), ptr(wp), None, None, None,
+                                                               ptr(stats), stream()))
+    except RuntimeError as e:
+        if "UNSUPPORTED" not in str(e):
+            raise
+        return None
+    scale = torch.empty(64, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    upd = bn.track_running_stats and bn.running_mean is not None
+    L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
+                     ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum),
+                     float(bn.eps), 1, ptr(scale), ptr(shift), None, None, 64, stream())
+    if upd and bn.num_batches_tracked is not None:
+        PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+    POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    y = torch.empty((B, POH, POW, 64), dtype=x.dtype, device=dev)
+    _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * 64,
+           lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 3, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(y), None, stream()))
+    return y

@@ -11,6 +11,8 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from ... import runtime
+from ...hip import conv as hconv
 from ...hip import ops as hops
 from .._nn import BatchNorm2d, Conv2d, conv_bn_act
 
@@ -61,8 +63,15 @@ class Trunk(nn.Sequential):
                 nn.init.constant_(m.bias, 0.0)
 
     def forward(self, x):
-        x = conv_bn_act(x, self[0], self[1], relu=True)
-        x = self[3](x)
+        pooled = None
+        if not torch.is_grad_enabled() or not any(p.requires_grad for p in (self[0].weight, self[1].weight, self[1].bias)):
+            cfg = hconv._Cfg(self[0].spec, self[0]._packed, self[1], True, runtime.loss_scale(), getattr(x, "orig_hw", None))
+            pooled = hconv.fused_stem_pool(x, self[0].weight, self[1], cfg)  # frozen stem: conv+BN+ReLU+maxpool in two light passes
+        if pooled is None:
+            x = conv_bn_act(x, self[0], self[1], relu=True)
+            x = self[3](x)
+        else:
+            x = pooled
         for i in range(4, 8):
             for blk in self[i]:
                 x = blk(x)

@@ -433,3 +433,37 @@ def test_train_step_hipgraph_matches_eager():
             close(finals[True][1][k], v, rtol=5e-3, atol=5e-4, what=k)
         else:
             assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked advanced identically
+
+
+def test_frozen_stem_fused_pool_matches_unfused():
+    """Frozen trunk, train-mode BN, fp16: the two-pass fused stem (statistics pass; conv+BN+ReLU+maxpool pass) must give
+    the trunk the same features and the same running statistics as conv -> BN -> ReLU -> MaxPool run separately."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    from self_driving_model_amd.models.experts.resnet import Trunk
+    from oracle import torch_ref as oref
+    ref = seed_module_(oref.resnet18_trunk(), 77)
+    x = seeded_tensor((2, 3, 390, 518), 78)  # stem output 195 x 259 -> pooled 98 x 130: ragged pooled tiles
+    res = {}
+    for fused in (False, True):
+        hc.FUSE_FIRST_LAYER = fused
+        t = Trunk()
+        t.load_state_dict(ref.state_dict())
+        t.to(_dev()).train()
+        for p_ in t.parameters():
+            p_.requires_grad = False
+        with runtime.precision(torch.float16):
+            y = t(hops.image_to_s2d(x.to(_dev()), torch.float16))
+        hc.flush_bn_counters()
+        res[fused] = (y.float().cpu(), {k: v.detach().float().cpu() for k, v in t.state_dict().items()})
+    hc.FUSE_FIRST_LAYER = True
+    ref.train()
+    with torch.no_grad():
+        yr = ref(x).permute(0, 2, 3, 1)
+    assert res[True][0].shape == yr.shape
+    assert rel_err(res[True][0], res[False][0]) < 2e-2
+    assert rel_err(res[True][0], yr) < 3e-2 and rel_err(res[False][0], yr) < 3e-2
+    for k in ("1.running_mean", "1.running_var", "1.num_batches_tracked"):
+        close(res[True][1][k], res[False][1][k], rtol=2e-3, atol=2e-4, what=k)
+        close(res[True][1][k], ref.state_dict()[k].float(), rtol=3e-3, atol=3e-4, what=k)
