@@ -176,6 +176,9 @@ def main():
         others = {}
         try:
             others["cfg2_drivable_expert_train_B16_img_s"] = bench_drivable(16, 5, 2)
+            others["cfg3_detection_expert_hungarian_train_B8_img_s"] = bench_detection(8, 5, 2)
+            others.update(bench_matcher())
+            others.update(bench_inference(model, 64, 20, 3))
             model.unfreeze_experts()
             step_b = GatingTrainStep(model, TRAIN_CFG)
             dt_b = timed_steps(lambda: step_b(batch), 3, 4, False)  # warm-up covers the hipGraph capture
@@ -211,6 +214,68 @@ def bench_drivable(B, steps, warmup):
 
     dt = timed_steps(run, steps, warmup, False)
     return round(B * steps / dt, 2)
+
+
+def bench_detection(B, steps, warmup):
+    """BASELINE configs[2]: detection expert + Hungarian matcher train step, batch 8 synthetic boxes, fp16."""
+    from self_driving_model_amd.models.experts import BDDDetectionExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m = BDDDetectionExpert(10, pretrained_backbone=False).to(dev).train()
+    b = synthetic.bdd_detection_batch(B, H, W, 10, 32, dev, seed=0)
+    loader = synthetic.SyntheticLoader(b, steps)
+    tr = BDDTrainer("detection", m, loader, loader, dev, {"learning_rate": 2e-4, "weight_decay": 1e-5, "epochs": 1, "run_name": "bench"})
+    dt = timed_steps(lambda: tr.train_step(b), steps, warmup, False)
+    return round(B * steps / dt, 2)
+
+
+def bench_matcher():
+    """Matcher-only micro-benchmark: device cost + batched LSAP vs scipy on the host, Q = 920."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from self_driving_model_amd.hip import matcher as hm
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    for B, ni in ((8, 18), (64, 64)):
+        cost = torch.randn(B, ni, 920, device=dev)
+        n = torch.full((B,), ni, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            hm.lsap_batched(cost, n, transposed_storage=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            hm.lsap_batched(cost, n, transposed_storage=True)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+        c = cost.cpu().numpy().transpose(0, 2, 1)
+        t0 = time.perf_counter()
+        for b in range(B):
+            linear_sum_assignment(c[b])
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        out[f"lsap_B{B}_920x{ni}_ms_gpu_vs_scipy"] = [round(gpu_ms, 3), round(cpu_ms, 3)]
+    return out
+
+
+@torch.no_grad()
+def bench_inference(model, B, runs, warmup):
+    """BASELINE configs[4]: AutoMoE inference (inference/run_automoe.py path), batch 64, fp16: p50 / p95 latency."""
+    from self_driving_model_amd.training import synthetic
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model.eval()
+    batch = synthetic.carla_sequence_batch(B, H, W, 10, dev, seed=1)
+    batch = {k: v for k, v in batch.items() if k != "waypoints"}
+    lat = []
+    for i in range(warmup + runs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(batch)
+        torch.cuda.synchronize()
+        if i >= warmup:
+            lat.append((time.perf_counter() - t0) * 1e3)
+    lat.sort()
+    model.train()
+    return {"cfg5_inference_B64_p50_ms": round(lat[len(lat) // 2], 2), "cfg5_inference_B64_p95_ms": round(lat[int(len(lat) * 0.95) - 1], 2)}
 
 
 if __name__ == "__main__":

@@ -27,7 +27,10 @@ struct ConvKParams {
   const float* bias;
   double* stats;
   int M, nk, ksteps_per_tap, Ktot, relu, mtiles, ntiles;
+  long long tap_off[AM_MAX_TAPS];  // element offset of tap t relative to a row's base pixel: (dy*IW + dx)*ldi
 };
+
+__device__ __attribute__((aligned(64))) unsigned char g_zero_line_v1[64];  // zero-padding source of the fast loader
 
 struct RowInfo {
   int img;  // image index, -1 when the row is past M
@@ -69,18 +72,21 @@ __device__ __forceinline__ uint4 gather_chunk(const am_conv_geom& g, const T* __
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p) {
+  constexpr int NTH = WM * WN * 64;        // 4 or 8 waves
+  constexpr int RPP = NTH / 4;             // tile rows covered per loader pass (4 threads per 64-byte row)
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 64 / (int)sizeof(T);   // elements per K-step
   constexpr int PITCH = 80;                 // LDS row pitch in bytes (64 + 16 pad)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AR = BM / 64;
-  constexpr int BCH = (BN * 4 + 255) / 256;
+  constexpr int AR = BM / RPP;
+  constexpr int BCH = (BN * 4 + NTH - 1) / NTH;
   constexpr int STAGE = (BM + BN) * PITCH;
-  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+  static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && AR >= 1, "4 or 8 waves per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* opix_s = reinterpret_cast<int*>(smem + 2 * STAGE);
+  constexpr int EPI_BYTES = sizeof(T) == 2 ? WM * WN * (TM * 32) * (TN * 64 + 16) : 0;
+  int* opix_s = reinterpret_cast<int*>(smem + (2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES));
 
   const am_conv_geom& g = p.g;
   const T* __restrict__ x = static_cast<const T*>(p.x);
@@ -98,14 +104,31 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     int dummy;
-    decode_row(g, m0 + (tid >> 2) + 64 * i, p.M, rows[i], dummy);
+    decode_row(g, m0 + (tid >> 2) + RPP * i, p.M, rows[i], dummy);
   }
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NTH) {
     RowInfo tmp;
     int op;
     decode_row(g, m0 + r, p.M, tmp, op);
     opix_s[r] = op;
   }
+  // Hoisted loader state (single-pixel runs): per row a base pointer and a tap-validity bitmask, so a K-step costs one
+  // 64-bit add and one select per 16-byte chunk instead of re-deriving pixel coordinates (the kernel was VALU-bound:
+  // 9 VALU instructions per MFMA measured with SQ_INSTS_VALU / SQ_INSTS_MFMA).
+  const bool multi = g.pix_shift < 31;
+  const T* a_base[AR];
+  unsigned a_mask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    a_base[i] = reinterpret_cast<const T*>(g_zero_line_v1);
+    a_mask[i] = 0u;
+    if (!multi && rows[i].img >= 0) {
+      a_base[i] = x + ((long long)(rows[i].img * g.IH + rows[i].iy0) * g.IW + rows[i].ix0) * g.ldi + g.x_coff + chunk * EPC;
+      for (int t = 0; t < g.ntaps; ++t)
+        a_mask[i] |= (((unsigned)(rows[i].iy0 + g.dy[t]) < (unsigned)g.IH && (unsigned)(rows[i].ix0 + g.dx[t]) < (unsigned)g.IW) ? 1u : 0u) << t;
+    }
+  }
+  int ld_tap = 0, ld_kin = 0;  // (tap, K-step inside the tap) of the NEXT tile to load: advanced incrementally
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -119,25 +142,35 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
   static_assert(BCH <= 2, "B tile loader handles at most 128 rows");
 
   auto load_tile = [&](int kk) {
-    const int tap = kk / p.ksteps_per_tap;
-    const int roff = (kk - tap * p.ksteps_per_tap) * BK + chunk * EPC;
-    const int dy = g.dy[tap], dx = g.dx[tap];
+    const int tap = ld_tap, kin = ld_kin;
+    if (++ld_kin == p.ksteps_per_tap) { ld_kin = 0; ++ld_tap; }
+    if (!multi) {
+      const long long uoff = p.tap_off[tap] + (long long)kin * BK;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < AR; ++i) ra[i] = gather_chunk<T>(g, x, rows[i], dy, dx, roff);
+      for (int i = 0; i < AR; ++i) {
+        const T* src = ((a_mask[i] >> tap) & 1u) ? a_base[i] + uoff : reinterpret_cast<const T*>(g_zero_line_v1);
+        ra[i] = *reinterpret_cast<const uint4*>(src);
+      }
+    } else {
+      const int roff = kin * BK + chunk * EPC;
+      const int dy = g.dy[tap], dx = g.dx[tap];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[i] = gather_chunk<T>(g, x, rows[i], dy, dx, roff);
+    }
     {
       // BN*4 chunks per K-step; when BN*4 < 256 the upper threads re-read a valid row (never stored)
       const T* wk = w + (size_t)kk * BK + (tid & 3) * EPC;
       rb0 = *reinterpret_cast<const uint4*>(wk + (size_t)(n0 + ((tid % (BN * 4)) >> 2)) * p.Ktot);
-      if constexpr (BCH > 1) rb1 = *reinterpret_cast<const uint4*>(wk + (size_t)(n0 + 64 + (tid >> 2)) * p.Ktot);
+      if constexpr (BCH > 1) rb1 = *reinterpret_cast<const uint4*>(wk + (size_t)(n0 + RPP + (tid >> 2)) * p.Ktot);
     }
   };
   auto store_tile = [&](int stage) {
     char* As = smem + stage * STAGE;
     char* Bs = As + BM * PITCH;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(As + ((tid >> 2) + 64 * i) * PITCH + chunk * 16) = ra[i];
-    if (BN * 4 >= 256 || tid < BN * 4) *reinterpret_cast<uint4*>(Bs + (tid >> 2) * PITCH + (tid & 3) * 16) = rb0;
-    if constexpr (BCH > 1) *reinterpret_cast<uint4*>(Bs + (64 + (tid >> 2)) * PITCH + (tid & 3) * 16) = rb1;
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(As + ((tid >> 2) + RPP * i) * PITCH + chunk * 16) = ra[i];
+    if (BN * 4 >= NTH || tid < BN * 4) *reinterpret_cast<uint4*>(Bs + (tid >> 2) * PITCH + (tid & 3) * 16) = rb0;
+    if constexpr (BCH > 1) *reinterpret_cast<uint4*>(Bs + (RPP + (tid >> 2)) * PITCH + (tid & 3) * 16) = rb1;
   };
 
   if (p.nk > 0) {
@@ -276,17 +309,35 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvKParams p) {
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvKParams& p, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * 80;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr size_t EPI = sizeof(T) == 2 ? (size_t)WM * WN * (TM * 32) * (TN * 64 + 16) : 0;  // staged f16 epilogue
   ConvKParams q = p;
   q.mtiles = am_cdiv(p.M, BM);
   q.ntiles = am_cdiv(p.g.N, BN);
-  const size_t lds = 2 * STAGE + BM * sizeof(int);
-  hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN>), dim3(q.mtiles * q.ntiles), dim3(256), lds, s, q);
+  const size_t lds = (2 * STAGE > EPI ? 2 * STAGE : EPI) + BM * sizeof(int);
+  static bool attr_done = false;
+  if (lds > 64 * 1024 && !attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_k<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN>), dim3(q.mtiles * q.ntiles), dim3(WM * WN * 64), lds, s, q);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
 
+static int big_tile_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AM_CONV_BIGTILE"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 template <typename T>
 int dispatch_conv(const ConvKParams& p, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    // 8-wave 256x128 tile: 87 FLOP per byte through the CU's L2->LDS path instead of 64 (the bound of the 128^2 tile)
+    if (p.g.N > 64 && p.M >= 256 * 256 && big_tile_mode() == 1) return launch_conv<T, 256, 128, 4, 2>(p, s);
+  }
   if (p.g.N > 64) return launch_conv<T, 128, 128, 2, 2>(p, s);
   if (p.g.N > 32) return launch_conv<T, 256, 64, 4, 1>(p, s);
   return launch_conv<T, 256, 32, 4, 1>(p, s);
@@ -522,6 +573,8 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   p.Ktot = g->ntaps * g->krun;
   p.relu = relu;
   p.mtiles = p.ntiles = 0;
+  for (int t = 0; t < AM_MAX_TAPS; ++t)
+    p.tap_off[t] = t < g->ntaps ? ((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16 && !use_v1_only()) {
     // 3-channel first layers on the space-to-depth image: weights-stationary patch kernel

@@ -452,3 +452,25 @@ def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
         cfg = hc._Cfg(s, hc.PackedWeights(), None, False, 1.0)
         raw = hc.conv_bn_act(x, w.to(_dev()), None, None, False, None, cfg, False)
     assert rel_err(nchw(raw, cout), yr_raw) < 2e-3
+
+
+@pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 2, 186, 181), (256, 256, 3, 1, 1, 8, 96, 100), (128, 256, 3, 2, 1, 2, 370, 361)])
+def test_conv_big_tile_variant_vs_torch(case):
+    """Problems with M >= 65536 rows and N > 64 take the 8-wave 256x128 tile: forward and statistics against torch."""
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, k, st, pad, B, H, W = case
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).half().float()
+    yr = F.conv2d(x, w, stride=st, padding=pad)
+    s = hc.ConvSpec(cin, cout, k, st, pad)
+    OH, OW = yr.shape[2], yr.shape[3]
+    assert B * OH * OW >= 65536
+    y = torch.zeros(B, OH, OW, cout, dtype=torch.float16, device=_dev())
+    stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
+    hc.conv_gemm(hc.fwd_geom(s, B, H, W, cin, cout, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), None, False, y, stats)
+    torch.cuda.synchronize()
+    close(nchw(y, cout), yr, rtol=3e-3, atol=3e-3)
+    st_ = stats.view(16, 2, cout).sum(0).cpu()
+    np.testing.assert_allclose(st_[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=1.0)
+    np.testing.assert_allclose(st_[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
