@@ -71,7 +71,7 @@ __device__ __forceinline__ uint4 gather_chunk(const am_conv_geom& g, const T* __
   return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool MULTI>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p) {
   constexpr int NTH = WM * WN * 64;        // 4 or 8 waves
   constexpr int RPP = NTH / 4;             // tile rows covered per loader pass (4 threads per 64-byte row)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
   // Hoisted loader state (single-pixel runs): per row a base pointer and a tap-validity bitmask, so a K-step costs one
   // 64-bit add and one select per 16-byte chunk instead of re-deriving pixel coordinates (the kernel was VALU-bound:
   // 9 VALU instructions per MFMA measured with SQ_INSTS_VALU / SQ_INSTS_MFMA).
-  const bool multi = g.pix_shift < 31;
+  constexpr bool multi = MULTI;  // runs that span several pixels (3-channel first layers) keep the general gather
   const T* a_base[AR];
   unsigned a_mask[AR];
 #pragma unroll
@@ -138,24 +138,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  uint4 ra[AR], rb0, rb1;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1;  // scalars, not an array: hipcc keeps an indexed array captured by the lambdas in scratch
+  static_assert(AR <= 4, "A loader handles at most 4 rows per thread");
   static_assert(BCH <= 2, "B tile loader handles at most 128 rows");
 
   auto load_tile = [&](int kk) {
     const int tap = ld_tap, kin = ld_kin;
     if (++ld_kin == p.ksteps_per_tap) { ld_kin = 0; ++ld_tap; }
-    if (!multi) {
+    if constexpr (!multi) {
       const long long uoff = p.tap_off[tap] + (long long)kin * BK;  // wave-uniform
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
+      auto fetch = [&](int i) {
         const T* src = ((a_mask[i] >> tap) & 1u) ? a_base[i] + uoff : reinterpret_cast<const T*>(g_zero_line_v1);
-        ra[i] = *reinterpret_cast<const uint4*>(src);
-      }
+        return *reinterpret_cast<const uint4*>(src);
+      };
+      ra0 = fetch(0);
+      if constexpr (AR > 1) ra1 = fetch(1);
+      if constexpr (AR > 2) ra2 = fetch(2);
+      if constexpr (AR > 3) ra3 = fetch(3);
     } else {
       const int roff = kin * BK + chunk * EPC;
       const int dy = g.dy[tap], dx = g.dx[tap];
-#pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = gather_chunk<T>(g, x, rows[i], dy, dx, roff);
+      ra0 = gather_chunk<T>(g, x, rows[0], dy, dx, roff);
+      if constexpr (AR > 1) ra1 = gather_chunk<T>(g, x, rows[1], dy, dx, roff);
+      if constexpr (AR > 2) ra2 = gather_chunk<T>(g, x, rows[2], dy, dx, roff);
+      if constexpr (AR > 3) ra3 = gather_chunk<T>(g, x, rows[3], dy, dx, roff);
     }
     {
       // BN*4 chunks per K-step; when BN*4 < 256 the upper threads re-read a valid row (never stored)
@@ -167,8 +173,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
   auto store_tile = [&](int stage) {
     char* As = smem + stage * STAGE;
     char* Bs = As + BM * PITCH;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(As + ((tid >> 2) + RPP * i) * PITCH + chunk * 16) = ra[i];
+    char* arow = As + (tid >> 2) * PITCH + chunk * 16;
+    *reinterpret_cast<uint4*>(arow) = ra0;
+    if constexpr (AR > 1) *reinterpret_cast<uint4*>(arow + RPP * PITCH) = ra1;
+    if constexpr (AR > 2) *reinterpret_cast<uint4*>(arow + 2 * RPP * PITCH) = ra2;
+    if constexpr (AR > 3) *reinterpret_cast<uint4*>(arow + 3 * RPP * PITCH) = ra3;
     if (BN * 4 >= NTH || tid < BN * 4) *reinterpret_cast<uint4*>(Bs + (tid >> 2) * PITCH + (tid & 3) * 16) = rb0;
     if constexpr (BCH > 1) *reinterpret_cast<uint4*>(Bs + (RPP + (tid >> 2)) * PITCH + (tid & 3) * 16) = rb1;
   };
@@ -306,8 +315,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_conv(const ConvKParams& p, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, bool MULTI>
+int launch_conv_m(const ConvKParams& p, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * 80;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr size_t EPI = sizeof(T) == 2 ? (size_t)WM * WN * (TM * 32) * (TN * 64 + 16) : 0;  // staged f16 epilogue
@@ -317,13 +326,18 @@ int launch_conv(const ConvKParams& p, hipStream_t s) {
   const size_t lds = (2 * STAGE > EPI ? 2 * STAGE : EPI) + BM * sizeof(int);
   static bool attr_done = false;
   if (lds > 64 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_k<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_k<T, BM, BN, WM, WN, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN>), dim3(q.mtiles * q.ntiles), dim3(WM * WN * 64), lds, s, q);
+  hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN, MULTI>), dim3(q.mtiles * q.ntiles), dim3(WM * WN * 64), lds, s, q);
   AM_CHECK_LAUNCH();
   return AM_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_conv(const ConvKParams& p, hipStream_t s) {
+  return p.g.pix_shift < 31 ? launch_conv_m<T, BM, BN, WM, WN, true>(p, s) : launch_conv_m<T, BM, BN, WM, WN, false>(p, s);
 }
 
 static int big_tile_mode() {
@@ -584,7 +598,9 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // small-M, deep-K layers (layer4, heads): the LDS-DMA kernel wins; large-M layers stay on the register-staged one
-    if ((long long)p.M <= 65536) {
+    static int ring_all = -1;
+    if (ring_all < 0) { const char* e = getenv("AM_CONV_RING_ALL"); ring_all = e ? atoi(e) : 0; }
+    if ((long long)p.M <= 65536 || g->N >= 256 || (ring_all && g->N > 64)) {
       rc = am_conv_gemm2_f16(g, x, w, bias, relu, y, stats, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
