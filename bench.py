@@ -115,10 +115,11 @@ def main():
     if args.gpus != world:
         if args.gpus > 1 and world == 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    local = local % max(torch.cuda.device_count(), 1)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")  # RCCL over xGMI
+        dist.init_process_group(backend=os.environ.get("AUTOMOE_DIST_BACKEND", "nccl"), init_method="env://")  # "nccl" = RCCL over xGMI
 
     from self_driving_model_amd import runtime
     from self_driving_model_amd.hip import conv as hconv

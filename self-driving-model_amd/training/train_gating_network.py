@@ -103,7 +103,9 @@ class GatingTrainStep:
         self.reducer.paused = True  # hooks must not launch collectives inside the capture
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # with a process group alive its watchdog thread touches the runtime concurrently: only police this thread
+            mode = "thread_local" if self.reducer.enabled else "global"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 losses = self._fwd_bwd(self._static_batch)
             self._graph, self._static_losses = g, losses
         except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
@@ -115,6 +117,12 @@ class GatingTrainStep:
             self._graph = None
             torch.cuda.synchronize()
         finally:
+            if self.reducer.enabled:
+                # graph and eager ranks issue different collectives: agree on one mode or deadlock
+                ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    self._graph, self.use_graph = None, False
             self.reducer.paused = self._graph is not None
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -467,3 +467,61 @@ def test_frozen_stem_fused_pool_matches_unfused():
     for k in ("1.running_mean", "1.running_var", "1.num_batches_tracked"):
         close(res[True][1][k], res[False][1][k], rtol=2e-3, atol=2e-4, what=k)
         close(res[True][1][k], ref.state_dict()[k].float(), rtol=3e-3, atol=3e-4, what=k)
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+from _seeded import seed_module_, seeded_tensor
+from oracle import torch_ref as oref
+from self_driving_model_amd import runtime
+from self_driving_model_amd.models.automoe import create_automoe_model
+from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="env://")   # both ranks share the one GPU of the test box; RCCL needs one GPU per rank
+cfg = {"experts": [{"type": "detection", "pretrained_backbone": False}, {"type": "drivable", "pretrained_backbone": False}],
+       "gating": {"processed_dim": 256, "hidden_dim": 128}, "context": {"type": "simple", "context_dim": 64}, "policy": {"num_waypoints": 10}}
+ref = seed_module_(oref.create_automoe_model(cfg, "cpu"), 7 + rank)        # ranks start DIFFERENT: the constructor broadcast must fix it
+runtime.set_compute_dtype(torch.float32)
+m = create_automoe_model(cfg, "cpu"); m.load_state_dict(ref.state_dict()); m.to("cuda:0"); m.freeze_experts(); m.train()
+for d in m.modules():
+    if isinstance(d, torch.nn.Dropout): d.p = 0.0
+step = GatingTrainStep(m, {"learning_rate": 1e-3, "weight_decay": 1e-4}, use_graph=(sys.argv[2] == "graph"))
+B = 2
+batch = {k: v.to("cuda:0") for k, v in {"image": seeded_tensor((B, 3, 64, 96), 100 + rank), "speed": seeded_tensor((B, 10), 110 + rank),
+         "steering": seeded_tensor((B, 10), 120 + rank), "throttle": seeded_tensor((B, 10), 130 + rank),
+         "brake": seeded_tensor((B, 10), 140 + rank), "waypoints": seeded_tensor((B, 10, 2), 150 + rank)}.items()}
+losses = [float(step(batch)["total_loss"]) for _ in range(5)]
+assert (step._graph is not None) == (sys.argv[2] == "graph"), "graph mode mismatch"
+flat = step.optimizer.flat_p.detach().cpu()
+gathered = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks diverged"
+torch.save({"flat": flat, "losses": losses}, os.path.join(sys.argv[3], f"out_{sys.argv[2]}_{rank}.pt"))
+dist.barrier(); dist.destroy_process_group()
+print("dp-ok", rank, losses[0], losses[-1])
+'''
+
+
+def test_data_parallel_train_step_two_ranks_graph_and_eager(tmp_path):
+    """Two processes (sharing the box's single GPU, gloo transport) run the data-parallel gating step: replicas must
+    stay bit-identical across ranks, and the hipGraph mode (one all-reduce after the replay) must follow the same
+    trajectory as the eager mode (bucketed all-reduce from autograd hooks)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    res = {}
+    for i, mode in enumerate(("eager", "graph")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29651 + i), str(script), root, mode, str(tmp_path)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        assert r.stdout.count("dp-ok") == 2
+        res[mode] = torch.load(tmp_path / f"out_{mode}_0.pt", weights_only=True)
+    assert res["eager"]["losses"][-1] < res["eager"]["losses"][0]
+    np.testing.assert_allclose(res["graph"]["losses"], res["eager"]["losses"], rtol=2e-3, atol=1e-4)
+    close(res["graph"]["flat"], res["eager"]["flat"], rtol=5e-3, atol=5e-4)
