@@ -597,9 +597,10 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
     rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
-    // small-M, deep-K layers (layer4, heads): the LDS-DMA kernel wins; large-M layers stay on the register-staged one
+    // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads
+    // into 64 channels) stays on the register-staged kernel
     static int ring_all = -1;
-    if (ring_all < 0) { const char* e = getenv("AM_CONV_RING_ALL"); ring_all = e ? atoi(e) : 0; }
+    if (ring_all < 0) { const char* e = getenv("AM_CONV_RING_ALL"); ring_all = e ? atoi(e) : 1; }
     if ((long long)p.M <= 65536 || g->N >= 256 || (ring_all && g->N > 64)) {
       rc = am_conv_gemm2_f16(g, x, w, bias, relu, y, stats, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;

@@ -1,0 +1,332 @@
+// Third-generation forward / dgrad gather-GEMM for f16 ("ring" kernel): same 3-stage LDS-DMA ring as conv_gemm3_k
+// (conv_gemm2.hip) with a main loop that is ONE basic block, so the compiler can overlap its parts:
+//   * tiles are fetched with buffer_load_dwordx4 ... lds through raw buffer descriptors: a lane whose tap falls outside
+//     the image asks for an out-of-range offset and the hardware writes zeros (no zero line, no 64-bit pointer select,
+//     no exec-masked branch); weights need no per-lane arithmetic at all (uniform K offset in soffset);
+//   * tap offsets live in the lanes of one VGPR (v_readlane with the uniform tap index) instead of a kernarg load per K-step, whose
+//     s_waitcnt lgkmcnt(0) used to drain the fragment reads too;
+//   * both k16 sub-steps' fragments are requested before the first MFMA and the loads of tile kk+2 are issued between
+//     them, so LDS latency is hidden behind the first MFMAs instead of being exposed four times per K-step.
+#include "am_common.h"
+#include <cstdlib>
+
+namespace amr {
+
+constexpr int RING_MAX_TAPS = 9;
+constexpr unsigned OOB = 0x80000000u;  // offsets at or above every buffer's num_records
+
+struct RingParams {
+  am_conv_geom g;
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  double* stats;
+  int M, nk, kpt, Ktot, relu, mtiles, ntiles;
+  unsigned x_bytes, w_bytes;
+  int tap_off[RING_MAX_TAPS];  // byte offset of tap t relative to the row's base pixel
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// 16 bytes per lane from a raw buffer (base, num_records = bytes) straight into LDS at dst + lane*16; offsets at or past
+// `bytes` deliver zeros.  Kept in a __device__ helper: the buffer-resource type does not exist in the host pass.
+__device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes, char* dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                           (lds_ptr)dst, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) {
+  constexpr int BKB = 64;                  // K-step in bytes (32 halves = two k16 MFMA sub-steps)
+  constexpr int NW = WM * WN, NTH = NW * 64, NSTG = 3;
+  typedef half_t T;
+  constexpr int RPI = 1024 / BKB;          // rows per wave-instruction (16)
+  constexpr int AI = BM / RPI / NW;        // A instructions per wave per K-step
+  constexpr int BI = BN / RPI / NW;
+  constexpr int NLOAD = AI + BI;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int STAGE = (BM + BN) * BKB;
+  static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1 && (BN / RPI) % NW == 0 && (BM / RPI) % NW == 0, "tile");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  int* opix_s = reinterpret_cast<int*>(smem + 4096);  // filled after the K-loop, inside the then-free stage buffers
+
+  const am_conv_geom& g = p.g;
+  T* __restrict__ y = static_cast<T*>(p.y);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int lb = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = lb / p.ntiles, nt = lb - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-lane loader state: instruction j of this wave covers tile rows (wid*AI + j)*16 + lane/4 ----
+  const int lrow = lane >> 2, cpos = lane & 3;
+  unsigned a_off[AI], a_mask[AI], b_off[BI];
+  const int hw = g.MH * g.MW;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int r = (wid * AI + j) * RPI + lrow;
+    const int c = cpos ^ ((r >> 2) & 3);  // source chunk for this LDS position
+    const int m = m0 + r;
+    unsigned mask = 0, off = 0;
+    if (m < p.M) {
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int my = rem / g.MW, mx = rem - my * g.MW;
+      const int iy0 = my * g.iys, ix0 = mx * g.ixs;
+      off = (unsigned)((((img * g.IH + iy0) * g.IW + ix0) * g.ldi + g.x_coff) * 2 + c * 16);
+      for (int t = 0; t < g.ntaps; ++t)
+        mask |= (((unsigned)(iy0 + g.dy[t]) < (unsigned)g.IH && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.IW) ? 1u : 0u) << t;
+    }
+    a_off[j] = off;
+    a_mask[j] = mask;
+  }
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int r = (wid * BI + j) * RPI + lrow;
+    const int c = cpos ^ ((r >> 2) & 3);
+    b_off[j] = (unsigned)((n0 + r) * p.Ktot * 2 + c * 16);  // rows past the packed matrix are out of range: zeros
+  }
+  int tapv = 0;  // lane t holds tap t's byte offset: one v_readlane per K-step instead of a kernarg load (or a scratch table)
+#pragma unroll
+  for (int t = 0; t < RING_MAX_TAPS; ++t) tapv = (lane == t) ? p.tap_off[t] : tapv;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // tile `kk` = (tap, kin): A rows gather [tap offset + kin*64 B) of each pixel's run, B rows K bytes [kk*64, +64)
+  auto issue_tile = [&](int kk, int tap, int kin, int stage) {
+    const int toff = __builtin_amdgcn_readlane(tapv, tap);
+    const unsigned uoff = (unsigned)(toff + kin * BKB);
+    char* As = smem + stage * STAGE + wid * (AI * 1024);
+    char* Bs = smem + stage * STAGE + BM * BKB + wid * (BI * 1024);
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const unsigned vo = ((a_mask[j] >> tap) & 1u) ? a_off[j] + uoff : OOB;
+      buffer_to_lds16(p.x, p.x_bytes, As + j * 1024, vo, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      buffer_to_lds16(p.w, p.w_bytes, Bs + j * 1024, b_off[j], kk * BKB);
+  };
+
+  // issue cursor (tile index, tap, K-step inside the tap), advanced without divisions.  Tiles past the last one are
+  // still issued (their taps have no validity bit: zeros into a stage nobody reads), so every K-step is the same
+  // straight-line code with the same vmcnt bookkeeping.
+  const int kpt = __builtin_amdgcn_readfirstlane(p.kpt), nk = __builtin_amdgcn_readfirstlane(p.nk);
+  int ikk = 0, itap = 0, ikin = 0;
+  auto advance = [&]() {
+    ++ikk;
+    const bool wrap = ikin + 1 == kpt;
+    ikin = wrap ? 0 : ikin + 1;
+    itap = wrap ? itap + 1 : itap;
+  };
+  issue_tile(ikk, itap, ikin, 0); advance();
+  issue_tile(ikk, itap, ikin, 1); advance();
+
+  // fragment read addressing: lane reads row (lane&31) of its 32-row sub-tile, 16-byte chunk (2*ks + lane>>5) ^ swz(row);
+  // swz(row) is the same for the TM (TN) sub-tiles of a lane because they are 32 rows apart
+  const int frow_a = wm * TM * 32 + (lane & 31);
+  const int frow_b = wn * TN * 32 + (lane & 31);
+  int fa[2], fb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int cidx = ks * 2 + (lane >> 5);
+    fa[ks] = frow_a * BKB + ((cidx ^ ((frow_a >> 2) & 3)) << 4);
+    fb[ks] = BM * BKB + frow_b * BKB + ((cidx ^ ((frow_b >> 2) & 3)) << 4);
+  }
+
+  // Software pipeline, rotated by half a K-step so that no fragment read is waited for right after it is issued:
+  //   top:    read k16 sub-step 1 of tile kk, issue the loads of tile kk+2 (into the stage of tile kk-1, which every wave
+  //           finished reading before the previous barrier), 8 MFMAs of sub-step 0 (fragments read last iteration)
+  //   middle: tile kk+1 has landed (at most tile kk+2's loads outstanding) -> barrier -> read its sub-step 0
+  //   bottom: 8 MFMAs of sub-step 1
+  half8_t a0[TM], b0[TN], a1[TM], b1[TN];
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < TM; ++t) a0[t] = *reinterpret_cast<const half8_t*>(smem + fa[0] + t * 32 * BKB);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) b0[t] = *reinterpret_cast<const half8_t*>(smem + fb[0] + t * 32 * BKB);
+
+  int stage = 0;
+  for (int kk = 0; kk < nk; ++kk) {
+    const char* S = smem + stage * STAGE;
+    const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a1[t] = *reinterpret_cast<const half8_t*>(S + fa[1] + t * 32 * BKB);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b1[t] = *reinterpret_cast<const half8_t*>(S + fb[1] + t * 32 * BKB);
+    issue_tile(ikk, itap, ikin, stage == 0 ? 2 : stage - 1);
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // own part of tile kk+1 landed, own reads of tile kk returned (so the next iteration may overwrite ... tile kk-1's
+    // stage is the one written above; tile kk's stage is written after the NEXT barrier)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOAD) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* Sn = smem + nstage * STAGE;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a0[t] = *reinterpret_cast<const half8_t*>(Sn + fa[0] + t * 32 * BKB);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b0[t] = *reinterpret_cast<const half8_t*>(Sn + fb[0] + t * 32 * BKB);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[tm], b1[tn], acc[tm][tn], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage = nstage;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles issued past the end
+  __syncthreads();  // all fragment reads done before the epilogue reuses the stage buffers
+
+  // ---- epilogue: BN statistics from the accumulators, bias, ReLU, LDS-staged 16-byte stores ----
+  for (int r = tid; r < BM; r += NTH) {  // output pixel of every tile row
+    const int m = m0 + r;
+    int op = -1;
+    if (m < p.M) {
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int my = rem / g.MW, mx = rem - my * g.MW;
+      op = (img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0;
+    }
+    opix_s[r] = op;
+  }
+
+  if (p.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        const int col = wn * TN * 32 + tn * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = s;
+        red[(wm * BN + col) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        s += (double)red[(a * BN + tid) * 2 + 0];
+        q += (double)red[(a * BN + tid) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)(lb % AM_STATS_REPLICAS) * 2 * g.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + g.N + n0 + tid, q);
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int SP = TN * 64 + 16;
+    char* stg = smem + 8192 + wid * (TM * 32) * SP;  // past the stats scratch and the output-pixel table
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+      const float bv = (p.bias != nullptr && col < g.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          float v = acc[tm][tn][r] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
+        }
+    }
+    // the wave reads back what its own lanes wrote: LDS executes a wave's accesses in order, so draining the
+    // writes is enough; the asm also stops the compiler from moving the (differently typed) reads above the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPRW = TN * 4;
+    const int ncols = (g.N + 7) & ~7;
+#pragma unroll
+    for (int it = 0; it < TM * TN * 2; ++it) {
+      const int q = it * 64 + lane;
+      const int row = q / CPRW, cc = q - row * CPRW;
+      const int op = opix_s[wm * TM * 32 + row];
+      const int col0 = n0 + wn * TN * 32 + cc * 8;
+      if (op >= 0 && col0 < ncols)
+        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_ring(const RingParams& p0, hipStream_t s) {
+  constexpr int STAGE = (BM + BN) * 64;
+  RingParams p = p0;
+  p.mtiles = am_cdiv(p.M, BM);
+  p.ntiles = am_cdiv(p.g.N, BN);
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr size_t EPI = 8192 + (size_t)WM * WN * (TM * 32) * (TN * 64 + 16);
+  const size_t lds = 3 * STAGE > EPI ? 3 * STAGE : EPI;
+  static bool attr_done = false;
+  if (lds > 64 * 1024 && !attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ring_k<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_ring_k<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(WM * WN * 64), lds, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+}  // namespace amr
+
+// Called by am_conv_gemm2_f16 (conv_gemm2.hip); returns AM_ERR_UNSUPPORTED when the shape is not covered.
+// `npad_rows` = rows of the packed weight matrix (am_conv_npad).
+int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+                     hipStream_t s) {
+  using namespace amr;
+  if (g->ntaps <= 0 || g->ntaps > RING_MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0 || g->N <= 64) return AM_ERR_UNSUPPORTED;
+  const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
+  const long long Ktot = (long long)g->ntaps * g->krun;
+  const long long w_bytes = (long long)am_conv_npad(g->N) * Ktot * 2;
+  if (x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
+  RingParams p;
+  p.g = *g;
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.stats = stats;
+  p.M = g->B * g->MH * g->MW;
+  p.Ktot = (int)Ktot;
+  p.relu = relu;
+  p.kpt = g->krun * 2 / 64;
+  p.nk = g->ntaps * p.kpt;
+  p.mtiles = p.ntiles = 0;
+  p.x_bytes = (unsigned)x_bytes;
+  p.w_bytes = (unsigned)w_bytes;
+  for (int t = 0; t < RING_MAX_TAPS; ++t)
+    p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
+  const long long mt256 = (p.M + 255) / 256;
+  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) return launch_ring<256, 256, 2, 4>(p, s);
+  static int n128 = -1;
+  if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
+  if (mt256 * ((g->N + 127) / 128) >= 256) return n128 == 1 ? launch_ring<256, 128, 2, 2>(p, s) : launch_ring<256, 128, 4, 2>(p, s);
+  return AM_ERR_UNSUPPORTED;
+}
