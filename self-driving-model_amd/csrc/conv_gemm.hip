@@ -556,6 +556,10 @@ int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const
                       hipStream_t s);  // conv_gemm2.hip
 int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
                     const float* shift, int relu, void* y, double* stats, hipStream_t s);  // conv_s2d.hip
+int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
+                              double* stats, hipStream_t s);  // conv_patch3.hip
+int am_conv3x3_c64n64_wreg_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
+                               double* stats, hipStream_t s);  // conv_patch2.hip
 int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                           hipStream_t s);  // conv_patch.hip
 
@@ -595,6 +599,12 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     rc = am_conv_s2d_f16(g, 0, x, w, bias, nullptr, nullptr, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
+    static int wreg = -1;
+    if (wreg < 0) { const char* e = getenv("AM_PATCH_WREG"); wreg = e ? atoi(e) : 2; }
+    if (wreg) {
+      rc = wreg == 2 ? am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, y, stats, s) : am_conv3x3_c64n64_wreg_f16(g, x, w, bias, relu, y, stats, s);
+      if (rc != AM_ERR_UNSUPPORTED) return rc;
+    }
     rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Wl = smem;
   char* patch0 = smem + W_BYTES;
-  float* red = reinterpret_cast<float*>(smem + W_BYTES + 2 * PATCH_SLOT);  // [2][64] cross-wave stats scratch (reused)
 
   const char* __restrict__ x = static_cast<const char*>(p.x);
   const char* __restrict__ w = static_cast<const char*>(p.w);
@@ -82,8 +81,15 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // running BN statistics of this lane's two output columns (n = lane&31 and +32), over rows handled by this lane
-  float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
+  // The MFMAs run "transposed" (A = weights, B = pixels): a lane owns ONE pixel column (rx) and, per 32-channel block tn,
+  // the 16 channels tn*32 + 8*(r>>2) + 4*kg + (r&3) -- four consecutive channels per register quad, so the epilogue
+  // converts and stages 8 bytes at a time and the BN statistics are plain (packed) vector adds into per-lane partial
+  // sums, folded across the 32 pixel lanes once at the end of the kernel.
+  f32x16 ssum[2], ssq[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[tn][r] = 0.f; ssq[tn][r] = 0.f; }
   const int rx = lane & 31, kg = lane >> 5;
   int buf = 0;
   for (; tile < p.ntiles; tile += gridDim.x) {
@@ -91,40 +97,59 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
     if (next < p.ntiles && !(p.dbg & 4)) issue_patch(next, buf ^ 1);
     const char* pt = patch0 + buf * PATCH_SLOT;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];  // [tn][tm]
+    if (p.dbg & 2) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
 
-    if (!(p.dbg & 2))
+    if (!(p.dbg & 2)) {
+      // 36 k16 steps (tap-major), software-pipelined by hand: the four fragment reads of step s+2 are issued before the
+      // four MFMAs of step s (the workgroup runs one wave per SIMD, so nothing else hides the LDS latency; left to
+      // itself hipcc issues each step's reads right before an s_waitcnt lgkmcnt(0)).
+      half8_t fa[3][2], fb[3][2];
+      const char* brow = Wl + (lane & 31) * WPITCH + kg * 16;
+      const int prow0 = (2 * wid) * PW + rx;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tap = kh * 3 + kw;
-        // patch pixel of this lane for its two tile rows (ry = 2*wid + tm)
-        const int pid0 = (2 * wid + kh) * PW + rx + kw;
-        const int pid1 = pid0 + PW;
-        const char* a0 = pt + pid0 * CB;
-        const char* a1 = pt + pid1 * CB;
-        const int s0 = (pid0 >> 1) & 7, s1 = (pid1 >> 1) & 7;
-        const char* b0 = Wl + (lane & 31) * WPITCH + tap * CB + kg * 16;
-        const char* b1 = b0 + 32 * WPITCH;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int ch = ks * 2 + kg;
-          const half8_t fa0 = *reinterpret_cast<const half8_t*>(a0 + ((ch ^ s0) << 4));
-          const half8_t fa1 = *reinterpret_cast<const half8_t*>(a1 + ((ch ^ s1) << 4));
-          const half8_t fb0 = *reinterpret_cast<const half8_t*>(b0 + ks * 32);
-          const half8_t fb1 = *reinterpret_cast<const half8_t*>(b1 + ks * 32);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb1, acc[1][1], 0, 0, 0);
+      for (int s = 0; s < 36 + 2; ++s) {
+        // counted wait for step s-2's fragments BEFORE this step's reads are issued (LDS returns in order: the reads of
+        // step s-1 stay in flight).  Spelled as the builtin so hipcc's own waitcnt pass sees it; by itself it emits
+        // lgkmcnt(0) after the new reads.
+        if (s >= 2) {
+          if (s < 37) __builtin_amdgcn_s_waitcnt(0xC47F);  // lgkmcnt(4)
+          else __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0)
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 36) {
+          const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
+          const int pid0 = prow0 + kh * PW + kw, pid1 = pid0 + PW;
+          const int ch = ks * 2 + kg;
+          fa[s % 3][0] = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((ch ^ ((pid0 >> 1) & 7)) << 4));
+          fa[s % 3][1] = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((ch ^ ((pid1 >> 1) & 7)) << 4));
+          fb[s % 3][0] = *reinterpret_cast<const half8_t*>(brow + tap * CB + ks * 32);
+          fb[s % 3][1] = *reinterpret_cast<const half8_t*>(brow + 32 * WPITCH + tap * CB + ks * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s >= 2) {
+          const int c = (s - 2) % 3;
+          if (s == 2) {  // first step starts from the constant zero: no per-tile accumulator clears
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][tm], z, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][tm], acc[tn][tm], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
@@ -135,36 +160,56 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
     __syncthreads();
     buf ^= 1;
 
-    // ---- epilogue: acc[tm][tn][r] = out(pixel (ry = 2*wid+tm, px = (r&3)+8*(r>>2)+4*kg), channel tn*32 + (lane&31)) ----
+    // ---- epilogue: acc[tn][tm][r] = out(pixel (ry = 2*wid+tm, px = rx), channel tn*32 + 8*(r>>2) + 4*kg + (r&3)) ----
     const int img = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - img * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    if (ty * TH + TH > p.H || tx * TW + TW > p.W) {
+      // edge tile: pixels outside the image are not conv outputs -- zero them so they stay out of the statistics
+      // (they are not stored either)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const bool ok = ty * TH + 2 * wid + tm < p.H && tx * TW + rx < p.W;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tn][tm][r] = ok ? acc[tn][tm][r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        ssum[tn] += acc[tn][tm];
+        ssq[tn] = __builtin_elementwise_fma(acc[tn][tm], acc[tn][tm], ssq[tn]);
+      }
+    if (p.bias != nullptr || p.relu) {  // not used by the BN trunk; kept for the generic conv contract
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bv = p.bias ? p.bias[tn * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] : 0.f;
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            float v = acc[tn][tm][r] + bv;
+            acc[tn][tm][r] = p.relu ? fmaxf(v, 0.f) : v;
+          }
+        }
+    }
     // Stage this wave's 64 pixels x 64 channels in its own KiB range of the patch buffer it just finished reading
-    // (the same range this wave refills by DMA next iteration, so no other wave touches it), then write whole
-    // 128-byte pixel rows with 16-byte stores.
+    // (the same range this wave refills by DMA next iteration, so no other wave touches it): 8-byte writes of four
+    // consecutive channels, then whole 128-byte pixel rows go out with 16-byte stores.
     constexpr int SP = 144;
     char* stg = const_cast<char*>(pt) + wid * 11 * 1024;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int col = tn * 32 + (lane & 31);
-      const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const bool rowok = ty * TH + 2 * wid + tm < p.H;
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int px = (r & 3) + 8 * (r >> 2) + 4 * kg;
-          const float a = acc[tm][tn][r];
-          if (rowok && tx * TW + px < p.W) {  // pixels outside the image are not conv outputs: keep them out of the statistics
-            st_s[tn] += a;
-            st_q[tn] += a * a;
-          }
-          float v = a + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
-          *reinterpret_cast<half_t*>(stg + (tm * 32 + px) * SP + col * 2) = (half_t)v;
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = {acc[tn][tm][4 * j], acc[tn][tm][4 * j + 1], acc[tn][tm][4 * j + 2], acc[tn][tm][4 * j + 3]};
+          *reinterpret_cast<half4_t*>(stg + (tm * 32 + rx) * SP + (tn * 32 + 8 * j + 4 * kg) * 2) = __builtin_convertvector(v, half4_t);
         }
-      }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (!(p.dbg & 1)) {
@@ -182,21 +227,26 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
   }
 
   if (p.stats != nullptr) {
-    // lanes l and l+32 hold the same columns: fold, then 4 waves -> LDS -> one fp64 atomic per column per workgroup
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      st_s[tn] += __shfl_xor(st_s[tn], 32, 64);
-      st_q[tn] += __shfl_xor(st_q[tn], 32, 64);
-    }
-    float* part = reinterpret_cast<float*>(smem + W_BYTES);  // [4 waves][64 cols][2] in the (now idle) patch area
+    // fold the 32 pixel lanes of each half-wave (xor < 32 stays inside the half), then 4 waves -> LDS -> one fp64 atomic
+    // per channel per workgroup
+    float* part = reinterpret_cast<float*>(smem + W_BYTES);  // [4 waves][64 channels][2] in the (now idle) patch area
     __syncthreads();
-    if (lane < 32) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        part[(wid * 64 + tn * 32 + lane) * 2 + 0] = st_s[tn];
-        part[(wid * 64 + tn * 32 + lane) * 2 + 1] = st_q[tn];
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = ssum[tn][r], qv = ssq[tn][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sv += __shfl_xor(sv, o, 64);
+          qv += __shfl_xor(qv, o, 64);
+        }
+        if (rx == 0) {
+          const int ch = tn * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+          part[(wid * 64 + ch) * 2 + 0] = sv;
+          part[(wid * 64 + ch) * 2 + 1] = qv;
+        }
       }
-    }
     __syncthreads();
     if (tid < 64) {
       double s = 0.0, q = 0.0;
@@ -209,7 +259,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64n64_k(const PatchParams p) {
       atomicAdd(st + 64 + tid, q);
     }
   }
-  (void)red;
+  (void)Wl;
 }
 
 }  // namespace amp

@@ -1,0 +1,307 @@
+// Weights-in-registers 3x3 / stride-1 / pad-1 convolution for 64 -> 64 channels, f16 (ResNet-18 layer1 and its dgrad),
+// two persistent workgroups per CU.
+//
+// Measured on conv_patch.hip (weights in LDS, one wave per SIMD): the 144 MFMAs of a tile run at the matrix-core peak,
+// but they are only ~30 % of the tile time -- patch DMA issue, BN statistics, f16 conversion, LDS staging and the global
+// stores all run on the same single wave per SIMD, serialised before and after the MFMA phase.  Here
+//   * a wave keeps the weights of ONE 32-channel block as MFMA A-fragments in registers (36 k16-steps x half8 = 144
+//     VGPRs), so two waves fit on a SIMD (<= 256 VGPRs each) and no weight fragment is ever read from LDS;
+//   * a workgroup is four waves (2 pixel halves x 2 channel blocks) with its own stream of 8x16-pixel tiles and its own
+//     double-buffered input patch (73 KiB of LDS), and TWO workgroups are resident per CU: their tile loops drift out of
+//     phase, so while one runs MFMAs the other runs its epilogue / issues its next patch DMA on the same SIMDs;
+//   * input patch: 10 x 18 pixels at a 144-byte LDS pitch (conflict-free ds_read_b128 without a swizzle, every
+//     (tap, k16-step) offset an instruction immediate), filled by buffer_load ... lds (out-of-range offsets give the
+//     zero padding);
+//   * MFMAs run "transposed" (A = weights, B = pixels): a lane owns one pixel and four consecutive channels per register
+//     quad -- packed adds / FMAs for the BN statistics, v_cvt_pk_f16_f32, 8-byte LDS staging writes, 16-byte stores;
+//   * stores are inline-asm buffer stores (see buffer_store16_asm) so that the patch prefetch stays in flight across them.
+#include "am_common.h"
+#include <cstdlib>
+
+namespace amp3 {
+
+constexpr int TH = 8, TW = 16;             // output tile of one group
+constexpr int PH = TH + 2, PW = TW + 2;    // input patch
+constexpr int PP = 144;                    // LDS bytes per patch pixel (9 chunks of 16 B, the last one padding)
+constexpr int NPIX = PH * PW;              // 180
+constexpr int NINST = (NPIX * 9 + 63) / 64;   // 26 wave-instructions of 64 x 16 B
+constexpr int PATCH_SLOT = NINST * 1024;      // 26624
+constexpr int IPW = (NINST + 3) / 4;          // instructions per wave of a group (7; the last ones are skipped)
+constexpr int WROW = 1152;                    // bytes per packed weight row (576 halves)
+constexpr int SP = 80;                        // staging pitch per output pixel: 32 channels x 2 B + 16 B pad
+constexpr int STG_WAVE = 64 * SP;             // 5120
+constexpr int PATCH_BYTES = 2 * PATCH_SLOT;   // double buffer
+constexpr int LDS_BYTES = PATCH_BYTES + 4 * STG_WAVE + 1024;  // 74752: two workgroups per CU
+constexpr unsigned OOB = 0xC0000000u;         // + any tile base stays above num_records (< 2^30)
+static_assert(64 * WROW <= PATCH_BYTES + 4 * STG_WAVE, "weights pass through the patch + staging area once");
+
+struct Patch3Params {
+  const void* x;
+  const void* w;   // packed [>=64][576] halves (gather-GEMM forward packing)
+  void* y;
+  double* stats;
+  int B, H, W, ldi, x_coff, ldo, y_coff;
+  int tiles_y, tiles_x, ntiles;
+  unsigned x_bytes, w_bytes, y_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes, char* dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                           (lds_ptr)dst, 16, voff, 0, 0, 0);
+}
+
+typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
+
+// 16-byte store through a raw buffer descriptor, as inline asm on purpose: hipcc's waitcnt pass puts s_waitcnt vmcnt(0)
+// in front of every store it can see while an LDS-DMA may be outstanding (it cannot prove the DMA source does not alias
+// the store), which would drain the patch prefetch and serialise the stores.  Offsets >= num_records are dropped by the
+// hardware, so out-of-image pixels need no branch and every wave issues the same number of stores (the counted vmcnt
+// wait below relies on that).
+__device__ __forceinline__ void buffer_store16_asm(rsrc_words_t v, rsrc_words_t rsrc, unsigned voff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  rsrc_words_t yr;
+  {
+    const unsigned long long ya = reinterpret_cast<unsigned long long>(p.y);
+    yr.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ya);
+    yr.y = __builtin_amdgcn_readfirstlane((int)((ya >> 32) & 0xffffu));
+    yr.z = __builtin_amdgcn_readfirstlane((int)p.y_bytes);
+    yr.w = 0x00020000;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wid, hsel = w4 >> 1, tn = w4 & 1;
+  const int rx = lane & 31, kg = lane >> 5;
+  // pixel of this lane inside a 2 x 16 pixel fragment.  ds_read_b128 is serviced in the fixed 16-lane groups
+  // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): at the 144-byte pitch a group is conflict free iff its 16 patch pixels
+  // differ mod 16, and the second fragment row starts 18 = 2 (mod 16) pixels later -- so row 1 is rotated by two columns.
+  const int frow = rx >> 4, fcol = rx < 16 ? rx : (rx + 14) & 15;
+
+  // ---- weights: global -> LDS (coalesced, once) -> registers.  wf[tap*4 + ks] = A fragment (row = channel tn*32 + rx,
+  // k chunk 2*ks + kg) ----
+  for (int inst = wid; inst < 64 * WROW / 1024; inst += 4) buffer_to_lds16(p.w, p.w_bytes, smem + inst * 1024, (unsigned)(inst * 1024 + lane * 16));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  half8_t wf[36];
+#pragma unroll
+  for (int s = 0; s < 36; ++s)
+    wf[s] = *reinterpret_cast<const half8_t*>(smem + (tn * 32 + rx) * WROW + (s >> 2) * 128 + (s & 3) * 32 + kg * 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // everyone holds its fragments: the patch area may be overwritten
+
+  const int row_bytes = p.W * p.ldi * 2, pix_bytes = p.ldi * 2;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  char* const gpatch = smem;
+
+  auto issue_patch = [&](int tile, int buf) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+    const unsigned tb = (unsigned)((((img * p.H + iy0) * p.W + ix0) * p.ldi + p.x_coff) * 2);  // wraps for the halo row/col: fine
+    char* dst = gpatch + buf * PATCH_SLOT + w4 * (IPW * 1024);
+    // LDS position q = (w4*IPW + i)*64 + lane -> patch pixel q/9, 16-byte chunk q%9 (chunk 8 = pad).  Recomputed per tile
+    // from an opaque copy of the lane id: values hipcc hoists out of the tile loop end up spilled, and a spill reload
+    // next to the LDS-DMA costs an s_waitcnt vmcnt(0).
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      if (w4 * IPW + i < NINST) {
+        const int q = (w4 * IPW + i) * 64 + ln;
+        const int pix = q / 9, cc = q - pix * 9;
+        const int prow = pix / PW, pcol = pix - prow * PW;
+        const bool ok = cc < 8 && pix < NPIX && (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pcol) < (unsigned)p.W;
+        const unsigned vo = ok ? tb + (unsigned)(prow * row_bytes + pcol * pix_bytes + cc * 16) : OOB;
+        buffer_to_lds16(p.x, p.x_bytes, dst + i * 1024, vo);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // per-lane partial BN sums of the lane's 16 channels, folded across pixel lanes at the end
+  f32x16 ssum, ssq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+
+  // fragment origin of this lane inside a patch: pixel fragment tm covers rows hsel*4 + tm*2 + frow, cols fcol
+  const int fbase = ((hsel * 4 + frow) * PW + fcol) * PP + kg * 16;
+  char* stg = smem + PATCH_BYTES + wid * STG_WAVE;
+
+  // Tile stream of this workgroup.  Workgroups are dispatched round-robin over the 8 XCDs (id & 7) and each XCD has its
+  // own L2, so XCD x works through the contiguous tile range [x*chunk, (x+1)*chunk) -- its resident workgroups sweep it
+  // side by side -- and the halo rows/columns shared by neighbouring tiles hit in that L2 instead of crossing the fabric
+  // (the mapping only affects speed, never correctness).
+  const int chunk = (p.ntiles + 7) >> 3, per_xcd = (int)(gridDim.x + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min((xcd + 1) * chunk, p.ntiles);
+  int tile = xcd * chunk + (int)(blockIdx.x >> 3);
+  if (tile < tend) issue_patch(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (tile + per_xcd < tend) issue_patch(tile + per_xcd, 1);
+
+  int buf = 0;
+  for (; tile < tend; tile += per_xcd) {
+    // ------------------------------- MFMA phase -------------------------------
+    // 36 k16 steps (tap-major), software-pipelined by hand: the two pixel-fragment reads of step s+1 are issued before
+    // the two MFMAs of step s.  The wait is the builtin so that hipcc's waitcnt pass sees it (by itself it emits
+    // lgkmcnt(0) right AFTER the newest reads).
+    const char* pt = gpatch + buf * PATCH_SLOT + fbase;
+    f32x16 acc[2];  // [tm]
+    half8_t fp[2][2];
+#pragma unroll
+    for (int s = 0; s < 36 + 1; ++s) {
+      if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments (issued one MFMA pair ago)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < 36) {
+        const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          fp[s & 1][tm] = *reinterpret_cast<const half8_t*>(pt + ((tm * 2 + kh) * PW + kw) * PP + ks * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s >= 1) {
+        const int c = (s - 1) & 1;
+        if (s == 1) {  // first step starts from the constant zero: no accumulator clears
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], fp[c][tm], z, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s - 1], fp[c][tm], acc[tm], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // This wave's share of the next patch (issued a whole epilogue + MFMA phase ago) and the previous tile's stores are
+    // done; after the barrier the next patch is complete and nobody reads the current one any more -- so the patch after
+    // next goes into the buffer just read, two tiles ahead of its use (an LDS-DMA from HBM takes longer than one MFMA
+    // phase under load).  Raw barrier + asm wait: __syncthreads() would do, the explicit form documents what is ordered.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tile + 2 * per_xcd < tend) issue_patch(tile + 2 * per_xcd, buf);
+    buf ^= 1;
+
+    // ------------------------------- epilogue -------------------------------
+    // acc[tm][r] = out(pixel (row hsel*4 + tm*2 + frow, col fcol), channel tn*32 + 8*(r>>2) + 4*kg + (r&3))
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    if (ty * TH + TH > p.H || tx * TW + TW > p.W) {
+      // edge tile: pixels outside the image are not conv outputs -- zero them so they stay out of the statistics
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const bool ok = ty * TH + hsel * 4 + tm * 2 + frow < p.H && tx * TW + fcol < p.W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = ok ? acc[tm][r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      ssum += acc[tm];
+      ssq = __builtin_elementwise_fma(acc[tm], acc[tm], ssq);
+    }
+    // stage 64 pixels x 32 channels in this wave's own area, then 64-byte half-rows go out with 16-byte stores
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const f32x4 v = {acc[tm][4 * jq], acc[tm][4 * jq + 1], acc[tm][4 * jq + 2], acc[tm][4 * jq + 3]};
+        *reinterpret_cast<half4_t*>(stg + (tm * 32 + frow * 16 + fcol) * SP + (8 * jq + 4 * kg) * 2) = __builtin_convertvector(v, half4_t);
+      }
+    // the wave reads back what its own lanes wrote (LDS executes a wave's accesses in order); the asm also keeps the
+    // compiler from moving the differently typed reads above the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = it * 64 + lane;
+      const int prow = q >> 2, cc = q & 3;  // prow = tm*32 + pixel
+      const int oy = ty * TH + hsel * 4 + (prow >> 5) * 2 + ((prow >> 4) & 1), ox = tx * TW + (prow & 15);
+      const unsigned vo = (oy < p.H && ox < p.W) ? (unsigned)((((img * p.H + oy) * p.W + ox) * p.ldo + p.y_coff + tn * 32 + cc * 8) * 2) : 0x80000000u;
+      buffer_store16_asm(*reinterpret_cast<const rsrc_words_t*>(stg + prow * SP + cc * 16), yr, vo);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the next tile's writes
+  }
+
+  if (p.stats != nullptr) {
+    // fold the 32 pixel lanes of each half-wave (xor < 32 stays inside the half), then the 4 waves that share a channel
+    // block -> LDS -> one fp64 atomic per channel per workgroup
+    float* part = reinterpret_cast<float*>(smem);  // [4 waves][32 channels][2] in the (now idle) patch area
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv = ssum[r], qv = ssq[r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        qv += __shfl_xor(qv, o, 64);
+      }
+      if (rx == 0) {
+        const int ch = 8 * (r >> 2) + 4 * kg + (r & 3);
+        part[(wid * 32 + ch) * 2 + 0] = sv;
+        part[(wid * 32 + ch) * 2 + 1] = qv;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int ctn = tid >> 5, ch = tid & 31;
+      double s = 0.0, q = 0.0;
+      for (int h = 0; h < 2; ++h) {
+        const int ww = h * 2 + ctn;
+        s += (double)part[(ww * 32 + ch) * 2 + 0];
+        q += (double)part[(ww * 32 + ch) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)(blockIdx.x % AM_STATS_REPLICAS) * 2 * 64;
+      atomicAdd(st + tid, s);
+      atomicAdd(st + 64 + tid, q);
+    }
+  }
+}
+
+}  // namespace amp3
+
+// Returns AM_ERR_UNSUPPORTED unless the geometry is exactly a dense 3x3 / stride 1 / pad 1, 64 -> 64 f16 convolution
+// (forward packing, tap order kh-major) without bias / ReLU epilogue, over a tensor small enough for 30-bit offsets.
+int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
+                              double* stats, hipStream_t s) {
+  using namespace amp3;
+  if (g->ntaps != 9 || g->krun != 64 || g->N != 64 || g->pix_shift != 31) return AM_ERR_UNSUPPORTED;
+  if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
+  if (g->MH != g->IH || g->MW != g->IW || g->OH != g->IH || g->OW != g->IW) return AM_ERR_UNSUPPORTED;
+  for (int t = 0; t < 9; ++t)
+    if (g->dy[t] != t / 3 - 1 || g->dx[t] != t % 3 - 1) return AM_ERR_UNSUPPORTED;
+  if (g->IW < TW || (long long)g->B * g->IH * g->IW < 64 * 1024) return AM_ERR_UNSUPPORTED;  // small problems: gather-GEMM
+  const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
+  const long long y_bytes = (long long)g->B * g->OH * g->OW * g->ldo * 2;
+  if (x_bytes >= (1ll << 30) || y_bytes >= (1ll << 31) || bias != nullptr || relu) return AM_ERR_UNSUPPORTED;  // BN trunk layers only
+  Patch3Params p;
+  p.x = x; p.w = w; p.y = y; p.stats = stats;
+  p.B = g->B; p.H = g->IH; p.W = g->IW; p.ldi = g->ldi; p.x_coff = g->x_coff; p.ldo = g->ldo; p.y_coff = g->y_coff;
+  p.tiles_y = am_cdiv(g->IH, TH);
+  p.tiles_x = am_cdiv(g->IW, TW);
+  p.ntiles = p.B * p.tiles_y * p.tiles_x;
+  p.x_bytes = (unsigned)x_bytes;
+  p.w_bytes = 64 * WROW;
+  p.y_bytes = (unsigned)y_bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64n64_duo_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int grid = p.ntiles < 512 ? ((p.ntiles + 7) & ~7) : 512;  // two persistent workgroups per CU, a multiple of the 8 XCDs
+  hipLaunchKernelGGL(conv3x3_c64n64_duo_k, dim3(grid), dim3(256), LDS_BYTES, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "automoe_hip.h")
-LIB_PATH = os.path.join(_PKG, "csrc", "libautomoe_hip.so")
+LIB_PATH = os.environ.get("AUTOMOE_HIP_LIB") or os.path.join(_PKG, "csrc", "libautomoe_hip.so")  # override: A/B builds
 
 AM_F32, AM_F16 = 0, 1
 AM_MAX_TAPS = 16
