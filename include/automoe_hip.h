@@ -114,6 +114,12 @@ int am_bn_finalize(const double* stats, int nrep, double count, const float* con
                    am_stream_t stream);
 int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                 int relu, void* y, int ldy, long long P, int C, am_stream_t stream);
+/* am_bn_finalize + am_bn_apply in one launch (same arguments and results; scale/shift stay on chip). */
+int am_bn_finalize_apply(int dtype, const double* stats, int nrep, double count, const float* conv_bias,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, int training, float* save_mean, float* save_rstd, const void* x,
+                         int ldx, const void* res, int ldr, int relu, void* y, int ldy, long long P, int C,
+                         am_stream_t stream);
 int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
                      const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
                      am_stream_t stream);

@@ -212,15 +212,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
+      // column (channel) sums over this lane's TM*16 rows: whole-vector adds / FMAs (v_pk_add_f32, v_pk_fma_f32 on register
+      // pairs), then a horizontal add.  Rows past M were fetched as zeros, so they add nothing.
+      f32x16 sv = acc[0][tn], qv = acc[0][tn] * acc[0][tn];
+#pragma unroll
+      for (int tm = 1; tm < TM; ++tm) {
+        sv += acc[tm][tn];
+        qv = __builtin_elementwise_fma(acc[tm][tn], acc[tm][tn], qv);
+      }
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[tm][tn][r];
-          s += v;
-          q += v * v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        s += sv[r];
+        q += qv[r];
+      }
       s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 32, 64);
       if (lane < 32) {
@@ -246,19 +251,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   {
     constexpr int SP = TN * 64 + 16;
     char* stg = smem + 8192 + wid * (TM * 32) * SP;  // past the stats scratch and the output-pixel table
+    if (p.bias == nullptr && !p.relu) {  // BN layers (almost every launch): convert and stage, nothing else
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
-      const float bv = (p.bias != nullptr && col < g.N) ? p.bias[col] : 0.f;
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          float v = acc[tm][tn][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
-          *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)acc[tm][tn][r];
+          }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+        const float bv = (p.bias != nullptr && col < g.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[tm][tn][r] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
+          }
+      }
     }
     // the wave reads back what its own lanes wrote: LDS executes a wave's accesses in order, so draining the
     // writes is enough; the asm also stops the compiler from moving the (differently typed) reads above the writes

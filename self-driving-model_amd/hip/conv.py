@@ -25,6 +25,12 @@ def _runtime():
     return runtime
 
 
+def _grad_ready(p) -> bool:
+    """Parameter with a preallocated, dense fp32 ``.grad`` on the same device (FusedAdamW's flat buffer views)."""
+    g = getattr(p, "grad", None)
+    return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == p.device
+
+
 def dt_code(dtype: torch.dtype) -> int:
     if dtype == torch.float16:
         return AM_F16
@@ -335,29 +341,34 @@ class ConvBnAct(torch.autograd.Function):
                     fused_first = False
             if not fused_first:
                 conv_gemm(g, x, wp, b, False, raw, stats, k_real=s.cin * s.k * s.k)
-            scale = torch.empty(cout, dtype=torch.float32, device=dev)
-            shift = torch.empty_like(scale)
-            mean = torch.empty_like(scale)
-            rstd = torch.empty_like(scale)
+            mean = torch.empty(cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
             momentum = bn.momentum if bn.momentum is not None else 0.1
             upd = use_batch and bn.track_running_stats and bn.running_mean is not None
-            L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), ptr(b) if use_batch else None, ptr(gamma), ptr(beta),
-                             ptr(bn.running_mean) if (upd or not use_batch) else None,
-                             ptr(bn.running_var) if (upd or not use_batch) else None, float(momentum), float(bn.eps),
-                             int(use_batch), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), cout, stream())
+            rmean = ptr(bn.running_mean) if (upd or not use_batch) else None
+            rvar = ptr(bn.running_var) if (upd or not use_batch) else None
             if upd and bn.num_batches_tracked is not None:
                 PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # bumped together by flush_bn_counters()
             if fused_first:
                 import ctypes
+                scale = torch.empty_like(mean)
+                shift = torch.empty_like(mean)
+                L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), ptr(b) if use_batch else None, ptr(gamma), ptr(beta),
+                                 rmean, rvar, float(momentum), float(bn.eps), int(use_batch), ptr(scale), ptr(shift), ptr(mean),
+                                 ptr(rstd), cout, stream())
                 _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * cout,
                        lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 2, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(raw), None, stream()))
                 return raw  # no graph: nothing requires grad
             y = torch.empty_like(raw)
-            L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
-                          residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
+            # statistics -> scale/shift -> normalise (+ residual, ReLU) in one launch; scale/shift never leave the chip
+            L.am_bn_finalize_apply(dt_code(dtype), ptr(stats), AM_STATS_REPLICAS, float(P), ptr(b) if use_batch else None,
+                                   ptr(gamma), ptr(beta), rmean, rvar, float(momentum), float(bn.eps), int(use_batch), ptr(mean),
+                                   ptr(rstd), ptr(raw), ldo, ptr(residual), residual.shape[-1] if residual is not None else 0,
+                                   int(cfg.relu), ptr(y), ldo, P, cout, stream())
             ctx.use_batch = use_batch
         ctx.cfg, ctx.geom = cfg, g
         ctx.has_res = residual is not None
+        ctx.bn_params = (gamma, beta)
         ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if (cfg.relu or bn is None) else None, mean, rstd)
         return y
 
@@ -381,11 +392,15 @@ class ConvBnAct(torch.autograd.Function):
                                cout, stream())
             coef = torch.empty(3 * cout, dtype=torch.float32, device=dev)
             need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-            if need_p:
+            gp, bp = ctx.bn_params
+            direct = (need_p and _runtime().direct_grads() and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
+                      and _grad_ready(gp) and _grad_ready(bp))
+            if need_p and not direct:
                 dgamma = torch.zeros(cout, dtype=torch.float32, device=dev)
                 dbeta = torch.zeros(cout, dtype=torch.float32, device=dev)
-            L.am_bn_bwd_finalize(ptr(sums), AM_STATS_REPLICAS, float(P), ptr(gamma), ptr(rstd), inv, ptr(dgamma), ptr(dbeta),
-                                 ptr(coef), cout, stream())
+            # the kernel accumulates (+=): in direct mode straight into the optimizer's gradient buffer
+            L.am_bn_bwd_finalize(ptr(sums), AM_STATS_REPLICAS, float(P), ptr(gamma), ptr(rstd), inv,
+                                 ptr(gp.grad) if direct else ptr(dgamma), ptr(bp.grad) if direct else ptr(dbeta), ptr(coef), cout, stream())
             if not ctx.use_batch:
                 coef[cout:].zero_()  # eval-mode BN: statistics are constants
             dz = torch.empty_like(dy)

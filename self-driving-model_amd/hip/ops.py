@@ -19,6 +19,17 @@ def _L():
     return _lib.get()
 
 
+def _runtime():
+    from .. import runtime
+    return runtime
+
+
+def _grad_ready(p) -> bool:
+    """Parameter with a preallocated, dense fp32 ``.grad`` on the same device (FusedAdamW's flat buffer views)."""
+    g = getattr(p, "grad", None)
+    return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == p.device
+
+
 # --------------------------------------------------------------------------------------------
 # boundary layout
 # --------------------------------------------------------------------------------------------
@@ -236,6 +247,7 @@ class LinearAct(torch.autograd.Function):
         ctx.relu = relu
         ctx.save_for_backward(x, W, y if relu else None)
         ctx.has_b = b is not None
+        ctx.params = (W, b)
         return y
 
     @staticmethod
@@ -249,6 +261,13 @@ class LinearAct(torch.autograd.Function):
             dx = torch.empty_like(x)
             _L().am_linear_bwd_input(ptr(dy), N, ptr(y), N, ptr(W), ptr(dx), K, M, N, K, 0, stream())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            Wp, bp = ctx.params
+            if (_runtime().direct_grads() and ctx.needs_input_grad[1] and _grad_ready(Wp)
+                    and (not ctx.has_b or (ctx.needs_input_grad[2] and _grad_ready(bp)))):
+                # the kernel accumulates (+=): straight into the optimizer's gradient buffer, nothing for autograd to add
+                _L().am_linear_bwd_weight(ptr(dy), N, ptr(y), N, ptr(x), K, ptr(Wp.grad), ptr(bp.grad) if ctx.has_b else None,
+                                          M, N, K, stream())
+                return dx, None, None, None
             dW = torch.zeros_like(W)
             db = torch.zeros(N, dtype=torch.float32, device=W.device) if ctx.has_b else None
             _L().am_linear_bwd_weight(ptr(dy), N, ptr(y), N, ptr(x), K, ptr(dW), ptr(db), M, N, K, stream())
@@ -266,6 +285,7 @@ class LayerNormFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         _L().am_layernorm_fwd(ptr(x), D, ptr(gamma), ptr(beta), float(eps), ptr(y), D, ptr(mean), ptr(rstd), M, D, stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -275,6 +295,10 @@ class LayerNormFn(torch.autograd.Function):
         M, D = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gp, bp = ctx.params
+        if _runtime().direct_grads() and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _grad_ready(gp) and _grad_ready(bp):
+            _L().am_layernorm_bwd(ptr(dy), D, ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), D, ptr(gp.grad), ptr(bp.grad), M, D, stream())
+            return dx, None, None, None
         dg = torch.zeros_like(gamma) if need_p else None
         db = torch.zeros_like(gamma) if need_p else None
         _L().am_layernorm_bwd(ptr(dy), D, ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), D, ptr(dg), ptr(db), M, D, stream())

@@ -28,6 +28,22 @@ def set_compute_dtype(dtype: torch.dtype, loss_scale: float | None = None):
         _STATE["loss_scale"] = float(loss_scale)
 
 
+_DIRECT_GRADS = False
+
+
+def set_direct_grads(on: bool) -> None:
+    """When on, the backward kernels of Linear / LayerNorm / BatchNorm parameters accumulate straight into ``param.grad``
+    (the flat fp32 gradient buffer of FusedAdamW, zeroed once per step) and autograd sees no gradient for them: saves
+    a zero-fill and an add launch per parameter.  Must stay off when something listens to autograd's accumulate hooks
+    (the eager bucketed all-reduce)."""
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(on)
+
+
+def direct_grads() -> bool:
+    return _DIRECT_GRADS
+
+
 def loss_scale() -> float:
     return _STATE["loss_scale"] if _STATE["dtype"] == torch.float16 else 1.0
 

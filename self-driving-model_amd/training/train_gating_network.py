@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (kept for API parity with the reference module namespace)
 
+from .. import runtime
 from ..models.automoe import create_automoe_model
 from . import synthetic
 from .ddp import DataParallel, GradBucketReducer
@@ -93,9 +94,15 @@ class GatingTrainStep:
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
-        pred = self.model(batch)
-        losses = compute_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
-        losses["total_loss"].backward()
+        # parameter gradients go straight into the flat buffer unless the bucketed all-reduce is listening to autograd's
+        # accumulate hooks (eager multi-rank mode)
+        runtime.set_direct_grads(not self.reducer.enabled or self.reducer.paused)
+        try:
+            pred = self.model(batch)
+            losses = compute_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
+            losses["total_loss"].backward()
+        finally:
+            runtime.set_direct_grads(False)
         return losses
 
     def _capture(self, batch):
