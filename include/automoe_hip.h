@@ -114,12 +114,6 @@ int am_bn_finalize(const double* stats, int nrep, double count, const float* con
                    am_stream_t stream);
 int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                 int relu, void* y, int ldy, long long P, int C, am_stream_t stream);
-/* am_bn_finalize + am_bn_apply in one launch (same arguments and results; scale/shift stay on chip). */
-int am_bn_finalize_apply(int dtype, const double* stats, int nrep, double count, const float* conv_bias,
-                         const float* gamma, const float* beta, float* running_mean, float* running_var,
-                         float momentum, float eps, int training, float* save_mean, float* save_rstd, const void* x,
-                         int ldx, const void* res, int ldr, int relu, void* y, int ldy, long long P, int C,
-                         am_stream_t stream);
 int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
                      const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
                      am_stream_t stream);
@@ -239,6 +233,11 @@ int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, flo
                   float eps, float weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
                   am_stream_t stream);
 int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_stream_t stream);
+
+/* Packed conv operands from the fp32 master weight (hip/conv.py pack_fwd / pack_dgrad layouts; the reference keeps plain
+ * OIHW nn.Conv2d weights, e.g. models/policy/trajectory_head.py:10-22): dst[i] = idx[i] < 0 ? 0 : (dtype)src[idx[i]].
+ * One launch rebuilds every layout of a layer after an optimizer step. */
+int am_gather_cast(int dtype, const float* src, const int* idx, void* dst, long long n, am_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,3 +22,15 @@ rows = [(e.key, e.count, e.self_device_time_total) for e in prof.key_averages() 
 rows.sort(key=lambda r: -r[1])
 for k, n, t in rows[:45]:
     print(f"{n:5d} {t/1e3:8.3f} ms  {k[:100]}")
+
+# ---- second pass: python call sites of the small-kernel ops ----
+import collections
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof2:
+    step(batch); torch.cuda.synchronize()
+sites = collections.Counter()
+for ev in prof2.events():
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::add_", "aten::clone", "aten::cat", "aten::mul", "aten::index_select", "aten::index_copy_", "aten::_to_copy"):
+        st = [f for f in (ev.stack or []) if "self-driving-model_amd" in f or "self_driving_model_amd" in f or "bench" in f or "training" in f]
+        sites[(ev.name, st[0][-90:] if st else "(autograd engine / no python frame)")] += 1
+for (n, s), c in sites.most_common(40):
+    print(f"{c:4d} {n:18s} {s}")

@@ -73,71 +73,6 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
   }
 }
 
-// am_bn_finalize + am_bn_apply in one launch (training or eval): every workgroup derives scale/shift for all C channels
-// from the fp64 sums into LDS (C x 32 doubles from L2 per workgroup: cheaper than a dependent ~8 us launch in front of
-// each of the ~60 BN applications of a step); workgroup 0 also updates the running statistics and saves mean / rstd.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_finalize_apply_k(const double* __restrict__ stats, int nrep, double count,
-                                                           const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* running_mean, float* running_var,
-                                                           float momentum, float eps, int training, float* save_mean,
-                                                           float* save_rstd, const T* __restrict__ x, int ldx,
-                                                           const T* __restrict__ res, int ldr, int relu, T* __restrict__ y, int ldy,
-                                                           long long P, int C) {
-  extern __shared__ float ss[];  // [2][C]: scale, shift
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float mean, rstd;
-    if (training) {
-      double s = 0.0, q = 0.0;
-      for (int r = 0; r < nrep; ++r) {
-        s += stats[(size_t)r * 2 * C + c];
-        q += stats[(size_t)r * 2 * C + C + c];
-      }
-      const double m0 = s / count;
-      double var = q / count - m0 * m0;
-      if (var < 0.0) var = 0.0;
-      const double m = m0 + (conv_bias ? (double)conv_bias[c] : 0.0);
-      mean = (float)m;
-      rstd = (float)(1.0 / sqrt(var + (double)eps));
-      if (blockIdx.x == 0 && running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-      }
-    } else {
-      mean = running_mean[c];
-      rstd = 1.0f / sqrtf(running_var[c] + eps);
-    }
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    ss[c] = g * rstd;
-    ss[C + c] = b - mean * g * rstd;
-    if (blockIdx.x == 0) {
-      if (save_mean) save_mean[c] = mean;
-      if (save_rstd) save_rstd[c] = rstd;
-    }
-  }
-  __syncthreads();
-  constexpr int E = 16 / (int)sizeof(T);
-  const int cpr = C / E;
-  const long long total = P * cpr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / cpr;
-    const int c0 = (int)(i - pix * cpr) * E;
-    Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
-    Vec16<T> rv;
-    if (res) rv = *reinterpret_cast<const Vec16<T>*>(res + pix * ldr + c0);
-    Vec16<T> out;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float v = am_to_f32(xv.v[e]) * ss[c0 + e] + ss[C + c0 + e];
-      if (res) v += am_to_f32(rv.v[e]);
-      if (relu) v = fmaxf(v, 0.f);
-      out.v[e] = am_from_f32<T>(v);
-    }
-    *reinterpret_cast<Vec16<T>*>(y + pix * ldy + c0) = out;
-  }
-}
-
 // One workgroup strides over pixel rows; thread t owns channel chunk (t % cpr) for rows t / cpr + k*rpb.
 // Partial sums stay in registers; block-level LDS reduce; fp64 atomics into replicas.
 template <typename T>
@@ -304,31 +239,6 @@ extern "C" int am_bn_finalize(const double* stats, int nrep, double count, const
 }
 
 #define AM_EW_CHECK(C, ld, es) (((C) * (es)) % 16 != 0 || ((ld) * (es)) % 16 != 0)
-
-extern "C" int am_bn_finalize_apply(int dtype, const double* stats, int nrep, double count, const float* conv_bias,
-                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                    float momentum, float eps, int training, float* save_mean, float* save_rstd, const void* x,
-                                    int ldx, const void* res, int ldr, int relu, void* y, int ldy, long long P, int C,
-                                    am_stream_t stream) {
-  const int es = dtype == AM_F16 ? 2 : 4;
-  if ((dtype != AM_F16 && dtype != AM_F32) || !x || !y || P < 0 || C <= 0) return AM_ERR_ARG;
-  if (training && (!stats || count <= 0.0)) return AM_ERR_ARG;
-  if (!training && (!running_mean || !running_var)) return AM_ERR_ARG;
-  if (AM_EW_CHECK(C, ldx, es) || (ldy * es) % 16 != 0 || (res && (ldr * es) % 16 != 0)) return AM_ERR_ARG;
-  if (C > 4096) return AM_ERR_UNSUPPORTED;  // scale/shift table lives in LDS
-  if (P == 0) return AM_OK;
-  // fewer, longer workgroups than the plain apply: each one pays the C x 2*nrep fp64 prologue
-  long long grid = P * (C * es / 16) / (256 * 8);
-  grid = grid < 256 ? 256 : (grid > 2048 ? 2048 : grid);
-  const size_t lds = (size_t)2 * C * sizeof(float);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == AM_F16)
-    hipLaunchKernelGGL(bn_finalize_apply_k<half_t>, dim3((int)grid), dim3(256), lds, s, stats, nrep, count, conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, save_mean, save_rstd, (const half_t*)x, ldx, (const half_t*)res, ldr, relu, (half_t*)y, ldy, P, C);
-  else
-    hipLaunchKernelGGL(bn_finalize_apply_k<float>, dim3((int)grid), dim3(256), lds, s, stats, nrep, count, conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, save_mean, save_rstd, (const float*)x, ldx, (const float*)res, ldr, relu, (float*)y, ldy, P, C);
-  AM_CHECK_LAUNCH();
-  return AM_OK;
-}
 
 extern "C" int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                            int relu, void* y, int ldy, long long P, int C, am_stream_t stream) {

@@ -68,6 +68,17 @@ inline int ew_grid(long long total) {
   return (int)b;
 }
 
+
+// dst[i] = idx[i] < 0 ? 0 : (T)src[idx[i]]: every packed conv operand (forward and dgrad layouts) of a layer, rebuilt
+// from the fp32 master weight in one launch after an optimizer step.
+template <typename T>
+__global__ void gather_cast_k(const float* __restrict__ src, const int* __restrict__ idx, T* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int j = idx[i];
+    dst[i] = j < 0 ? (T)0.f : (T)src[j];
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -97,6 +108,15 @@ extern "C" int am_scale_inplace(float* x, long long n, float mul, const double* 
   if (!x || n < 0) return AM_ERR_ARG;
   if (n == 0) return AM_OK;
   hipLaunchKernelGGL(scale_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), x, n, mul, denom);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gather_cast(int dtype, const float* src, const int* idx, void* dst, long long n, am_stream_t stream) {
+  if ((dtype != AM_F16 && dtype != AM_F32) || !src || !idx || !dst || n < 0) return AM_ERR_ARG;
+  if (n == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(gather_cast_k<half_t>, dim3(ew_grid(n)), dim3(256), 0, ST(stream), src, idx, (half_t*)dst, n);
+  else hipLaunchKernelGGL(gather_cast_k<float>, dim3(ew_grid(n)), dim3(256), 0, ST(stream), src, idx, (float*)dst, n);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
