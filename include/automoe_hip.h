@@ -205,6 +205,14 @@ int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p
                    const long long* dev_step, am_stream_t stream);
 int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, am_stream_t stream);
 
+/* Gating-stage objective (training/train_gating_network.py:21-76 compute_gating_losses) and its gradient in one launch:
+ * parts6 = {ade, fde, speed, smoothness, load_balancing, entropy}, total = coef6 . parts6 (one float);
+ * g_* = d total / d input (dense).
+ * coef6 is a HOST array.  wp/twp [B,T,2] dense; spd/tspd [B,S] with row strides ld_* (S = 0: no speed term); w [B,E], E <= 64. */
+int am_gating_losses(const float* wp, const float* twp, int B, int T, const float* spd, const float* tspd, int ld_spd,
+                     int ld_tspd, int S, const float* w, int E, const float* coef6, int use_lb, int use_ent,
+                     float* total, float* parts6, float* g_wp, float* g_spd, float* g_w, am_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Hungarian matcher (training/hungarian_matcher.py:20-85).
  *   am_match_cost    per image b and query q: C = w_bbox*L1(cxcywh) + w_class*(-softmax prob at the

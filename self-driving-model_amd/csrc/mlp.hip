@@ -303,6 +303,111 @@ inline int ew_grid(long long total) {
   return (int)b;
 }
 
+
+// Gating-stage objective and its gradient in one single-workgroup launch (B*T*2 ~ 500 elements; ~70 tiny torch launches
+// otherwise).  L1 means use sign(0) = 0 like torch's abs backward.
+//   ade = mean|wp - twp|, fde = mean|wp[:,T-1] - twp[:,T-1]|, speed = mean|spd - tspd|, smooth = mean|d[t+1] - d[t]| with
+//   d[t] = wp[t+1] - wp[t], lb = mean_e (mean_b w[b,e] - 1/E)^2, ent = mean_b sum_e w log(w + 1e-8);
+//   total = cw[0] ade + cw[1] fde + cw[2] speed + cw[3] smooth + cw[4] lb + cw[5] ent.
+struct GatingLossArgs {
+  const float* wp; const float* twp; int B, T;
+  const float* spd; const float* tspd; int ld_spd, ld_tspd, S;  // S == 0: no speed term
+  const float* w; int E;
+  float cw[6];
+  int use_lb, use_ent;
+  float* total;   // scalar
+  float* parts;   // [6]: ade, fde, speed, smooth, lb, ent
+  float* g_wp; float* g_spd; float* g_w;  // d total / d input (dense [B,T,2], [B,S], [B,E])
+};
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__device__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void gating_losses_k(const GatingLossArgs a) {
+  __shared__ float red[4];
+  __shared__ float usage[64];
+  const int tid = threadIdx.x;
+  const int B = a.B, T = a.T, E = a.E, S = a.S;
+  const int nwp = B * T * 2;
+  const float c_ade = a.cw[0] / (float)nwp, c_fde = a.cw[1] / (float)(B * 2);
+  const int nsm = T > 2 ? B * (T - 2) * 2 : 0;
+  const float c_sm = nsm > 0 ? a.cw[3] / (float)nsm : 0.f;
+  float s_ade = 0.f, s_fde = 0.f, s_sm = 0.f;
+  for (int i = tid; i < nwp; i += blockDim.x) {
+    const int c = i & 1, t = (i >> 1) % T, b = i / (2 * T);
+    const float* row = a.wp + (size_t)b * T * 2;
+    const float v = row[t * 2 + c], d = v - a.twp[i];
+    s_ade += fabsf(d);
+    float g = c_ade * sgn(d);
+    if (t == T - 1) { s_fde += fabsf(d); g += c_fde * sgn(d); }
+    // second differences q(u) = wp[u+2] - 2 wp[u+1] + wp[u], u = 0..T-3; element t appears in q(t), q(t-1), q(t-2)
+    if (t + 2 < T) {
+      const float q = row[(t + 2) * 2 + c] - 2.f * row[(t + 1) * 2 + c] + v;
+      s_sm += fabsf(q);
+      g += c_sm * sgn(q);
+    }
+    if (t >= 1 && t + 1 < T) {
+      const float q = row[(t + 1) * 2 + c] - 2.f * v + row[(t - 1) * 2 + c];
+      g -= 2.f * c_sm * sgn(q);
+    }
+    if (t >= 2) {
+      const float q = v - 2.f * row[(t - 1) * 2 + c] + row[(t - 2) * 2 + c];
+      g += c_sm * sgn(q);
+    }
+    a.g_wp[i] = g;
+  }
+  float s_spd = 0.f;
+  if (S > 0) {
+    const float c_spd = a.cw[2] / (float)(B * S);
+    for (int i = tid; i < B * S; i += blockDim.x) {
+      const int b = i / S, k = i - b * S;
+      const float d = a.spd[(size_t)b * a.ld_spd + k] - a.tspd[(size_t)b * a.ld_tspd + k];
+      s_spd += fabsf(d);
+      a.g_spd[i] = c_spd * sgn(d);
+    }
+  }
+  // expert usage (E <= 64)
+  if (tid < E) {
+    float u = 0.f;
+    for (int b = 0; b < B; ++b) u += a.w[(size_t)b * E + tid];
+    usage[tid] = u / (float)B;
+  }
+  __syncthreads();
+  float s_ent = 0.f, s_lb = 0.f;
+  if (tid < E && a.use_lb) { const float d = usage[tid] - 1.f / (float)E; s_lb = d * d; }
+  for (int i = tid; i < B * E; i += blockDim.x) {
+    const int e = i % E;
+    const float wv = a.w[i];
+    float g = 0.f;
+    if (a.use_ent) {
+      const float lg = logf(wv + 1e-8f);
+      s_ent += wv * lg;
+      g += a.cw[5] / (float)B * (lg + wv / (wv + 1e-8f));
+    }
+    if (a.use_lb) g += a.cw[4] * 2.f / (float)E * (usage[e] - 1.f / (float)E) / (float)B;
+    a.g_w[i] = g;
+  }
+  const float ade = block_sum(s_ade, red) / (float)nwp;
+  const float fde = block_sum(s_fde, red) / (float)(B * 2);
+  const float sm = nsm > 0 ? block_sum(s_sm, red) / (float)nsm : __builtin_nanf("");  // torch: mean of an empty tensor (T <= 2)
+  const float spd = S > 0 ? block_sum(s_spd, red) / (float)(B * S) : 0.f;
+  const float lb = a.use_lb ? block_sum(s_lb, red) / (float)E : 0.f;
+  const float ent = a.use_ent ? block_sum(s_ent, red) / (float)B : 0.f;
+  if (tid == 0) {
+    a.total[0] = a.cw[0] * ade + a.cw[1] * fde + a.cw[2] * spd + a.cw[3] * sm + a.cw[4] * lb + a.cw[5] * ent;
+    a.parts[0] = ade; a.parts[1] = fde; a.parts[2] = spd; a.parts[3] = sm; a.parts[4] = lb; a.parts[5] = ent;
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -397,6 +502,23 @@ extern "C" int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, l
   if (!dy || !dx || !mask || n < 0 || p < 0.f || p >= 1.f) return AM_ERR_ARG;
   if (n == 0) return AM_OK;
   hipLaunchKernelGGL(dropout_bwd_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), dy, mask, dx, n, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_gating_losses(const float* wp, const float* twp, int B, int T, const float* spd, const float* tspd, int ld_spd,
+                                int ld_tspd, int S, const float* w, int E, const float* coef6, int use_lb, int use_ent,
+                                float* total, float* parts6, float* g_wp, float* g_spd, float* g_w, am_stream_t stream) {
+  if (!wp || !twp || !w || !coef6 || !total || !parts6 || !g_wp || !g_w || B <= 0 || T <= 0 || E <= 0 || E > 64 || S < 0) return AM_ERR_ARG;
+  if (S > 0 && (!spd || !tspd || !g_spd)) return AM_ERR_ARG;
+  GatingLossArgs a;
+  a.wp = wp; a.twp = twp; a.B = B; a.T = T;
+  a.spd = spd; a.tspd = tspd; a.ld_spd = ld_spd; a.ld_tspd = ld_tspd; a.S = S;
+  a.w = w; a.E = E;
+  for (int i = 0; i < 6; ++i) a.cw[i] = coef6[i];
+  a.use_lb = use_lb; a.use_ent = use_ent;
+  a.total = total; a.parts = parts6; a.g_wp = g_wp; a.g_spd = g_spd; a.g_w = g_w;
+  hipLaunchKernelGGL(gating_losses_k, dim3(1), dim3(256), 0, ST(stream), a);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

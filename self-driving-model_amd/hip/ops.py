@@ -372,3 +372,39 @@ class GateCombine(torch.autograd.Function):
         _L().am_gate_combine_bwd(ptr(logits), _ptr_array(processed), E, D, temperature, use_softmax, top_k, ptr(dcombined),
                                  ptr(dweights), ptr(dlogits), _ptr_array(dproc), B, D, stream())
         return (dlogits, None, None, None, *dproc)
+
+
+class GatingLosses(torch.autograd.Function):
+    """compute_gating_losses (reference training/train_gating_network.py:21-76) and its gradient in ONE launch.
+    Returns (total, parts) with parts = [ade, fde, speed, smoothness, load_balancing, entropy]; gradients flow from `total`
+    only -- the parts are reporting values (non-differentiable), as in the reference's training loop."""
+
+    @staticmethod
+    def forward(ctx, wp, twp, spd, tspd, w, coef, use_lb: bool, use_ent: bool):
+        require_hip(wp, "waypoints")
+        wp, twp, w = wp.contiguous().float(), twp.contiguous().float(), w.contiguous().float()
+        B, T = wp.shape[0], wp.shape[1]
+        E = w.shape[1]
+        S = 0
+        if spd is not None:
+            spd = spd.float()
+            tspd = tspd.float()
+            assert spd.stride(1) == 1 and tspd.stride(1) == 1 and spd.shape == tspd.shape
+            S = spd.shape[1]
+        total = torch.empty((), dtype=torch.float32, device=wp.device)
+        parts = torch.empty(6, dtype=torch.float32, device=wp.device)
+        g_wp = torch.empty_like(wp)
+        g_w = torch.empty_like(w)
+        g_spd = torch.empty((B, S), dtype=torch.float32, device=wp.device) if S else None
+        c = (ctypes.c_float * 6)(*[float(v) for v in coef])
+        _L().am_gating_losses(ptr(wp), ptr(twp), B, T, ptr(spd) if S else None, ptr(tspd) if S else None,
+                              spd.stride(0) if S else 0, tspd.stride(0) if S else 0, S, ptr(w), E, c, int(use_lb), int(use_ent),
+                              ptr(total), ptr(parts), ptr(g_wp), ptr(g_spd) if S else None, ptr(g_w), stream())
+        ctx.save_for_backward(g_wp, g_spd, g_w)
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, s, _dparts):
+        g_wp, g_spd, g_w = ctx.saved_tensors  # d total / d input; s = d objective / d total
+        return g_wp * s, None, (g_spd * s if g_spd is not None else None), None, g_w * s, None, None, None

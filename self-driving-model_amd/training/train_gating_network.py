@@ -62,6 +62,27 @@ def compute_gating_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor
             "load_balancing": load_balancing_loss, "entropy": entropy_loss}
 
 
+def fused_gating_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor, target_spd: torch.Tensor,
+                        config: Dict) -> Dict[str, torch.Tensor]:
+    """compute_gating_losses as one HIP launch (forward values + gradient): same dictionary, same arithmetic in fp32."""
+    from ..hip import ops as hops
+    wp = pred["waypoints"]
+    pred_spd = pred.get("speed_seq", pred.get("speed"))
+    spd = tspd = None
+    if pred_spd is not None and pred_spd.dim() == 2 and target_spd.dim() == 2 and pred_spd.size(1) == target_spd.size(1):
+        spd, tspd = pred_spd, target_spd
+    else:
+        pred_last = pred.get("speed")
+        if pred_last is not None and pred_last.dim() == 2 and pred_last.size(1) == 1:
+            spd, tspd = pred_last, target_spd[:, -1:]
+    coef = [config.get("ade_weight", 1.0), config.get("fde_weight", 2.0), config.get("speed_weight", 0.2),
+            config.get("smoothness_weight", 0.1), config.get("load_balancing_weight", 0.01), config.get("entropy_weight", 0.001)]
+    total, v = hops.GatingLosses.apply(wp, target_wp, spd, tspd, pred["expert_weights"], coef,
+                                       bool(config.get("use_load_balancing", True)), bool(config.get("use_entropy_loss", True)))
+    return {"total_loss": total, "ade": v[0], "fde": v[1], "speed": v[2], "smoothness": v[3], "load_balancing": v[4],
+            "entropy": v[5]}
+
+
 class GatingTrainStep:
     """One optimisation step of the gating stage: zero_grad -> forward -> losses -> backward (+ overlapped
     all-reduce) -> clip 1.0 + AdamW.  Holds the optimizer / reducer pair so callers (trainer, bench) share it.
@@ -99,7 +120,7 @@ class GatingTrainStep:
         runtime.set_direct_grads(not self.reducer.enabled or self.reducer.paused)
         try:
             pred = self.model(batch)
-            losses = compute_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
+            losses = fused_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
             losses["total_loss"].backward()
         finally:
             runtime.set_direct_grads(False)
@@ -131,6 +152,12 @@ class GatingTrainStep:
                 if int(ok.item()) == 0:
                     self._graph, self.use_graph = None, False
             self.reducer.paused = self._graph is not None
+
+    @property
+    def input_buffers(self):
+        """The graph's static input tensors once the step is captured (None before): a loader that writes its host-to-device
+        copies straight into them (or passes them back to ``__call__``) saves the per-step device-to-device copy."""
+        return self._static_batch if self._graph is not None else None
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:

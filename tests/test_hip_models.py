@@ -401,6 +401,49 @@ def test_fused_upsample_pool_matches_unfused_and_oracle():
         close(g_f[n], g_u[n], rtol=2e-3, atol=1e-5, what=n)
 
 
+@pytest.mark.parametrize("speed_mode", ["seq", "last", "none"])
+@pytest.mark.parametrize("flags", [(True, True), (False, True), (True, False)])
+def test_fused_gating_losses_match_oracle_values_and_gradients(speed_mode, flags):
+    """One-launch gating objective (am_gating_losses) vs the oracle's restatement of the reference's
+    compute_gating_losses (training/train_gating_network.py:21-76) on CPU: the seven values and d total / d inputs,
+    fp32 tolerance.  Ragged cases: horizon 2 (no smoothness term), speed as a sequence / last step only / absent."""
+    from oracle.losses import gating_losses as oracle_losses
+    from self_driving_model_amd.training.train_gating_network import fused_gating_losses
+    dev = torch.device("cuda:0")
+    cfg = {"use_load_balancing": flags[0], "use_entropy_loss": flags[1], "ade_weight": 1.0, "fde_weight": 2.0, "speed_weight": 0.2,
+           "smoothness_weight": 0.1, "load_balancing_weight": 0.01, "entropy_weight": 0.001}
+    for B, T, E in [(5, 8, 3), (32, 8, 3), (3, 2, 4)]:
+        wp = seeded_tensor((B, T, 2), seed=11 + B)
+        twp = seeded_tensor((B, T, 2), seed=12 + B)
+        twp[0, 0, 0] = wp[0, 0, 0]  # an exact zero residual: sign(0) = 0 on both sides
+        w = torch.softmax(seeded_tensor((B, E), seed=13 + B), dim=1)
+        tspd = seeded_tensor((B, T), seed=14 + B)
+        spd = {"seq": seeded_tensor((B, T), seed=15 + B), "last": seeded_tensor((B, 1), seed=16 + B), "none": None}[speed_mode]
+
+        def run(fn, device):
+            a = wp.clone().to(device).requires_grad_(True)
+            ww = w.clone().to(device).requires_grad_(True)
+            pred = {"waypoints": a, "expert_weights": ww}
+            sp = None
+            if spd is not None:
+                sp = spd.clone().to(device).requires_grad_(True)
+                pred["speed_seq" if speed_mode == "seq" else "speed"] = sp
+            out = fn(pred, twp.to(device), tspd.to(device), cfg)
+            out["total_loss"].backward()
+            grads = [a.grad.cpu(), ww.grad.cpu()] + ([sp.grad.cpu()] if sp is not None else [])
+            return {k: float(v) for k, v in out.items()}, grads
+
+        ref_v, ref_g = run(oracle_losses, "cpu")
+        hip_v, hip_g = run(fused_gating_losses, dev)
+        for k in ref_v:
+            if np.isnan(ref_v[k]):  # horizon 2: the reference's smoothness term is the mean of an empty tensor
+                assert np.isnan(hip_v[k]), (k, hip_v[k])
+            else:
+                assert abs(hip_v[k] - ref_v[k]) <= 1e-5 + 1e-4 * abs(ref_v[k]), (k, hip_v[k], ref_v[k])
+        for gh, gr in zip(hip_g, ref_g):
+            np.testing.assert_allclose(gh.numpy(), gr.numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_train_step_hipgraph_matches_eager():
     """GatingTrainStep with the forward/backward captured in a hipGraph must walk the same parameter trajectory as the
     eager step (dropout off so both are deterministic up to fp32 atomics order)."""
