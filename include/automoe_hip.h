@@ -227,6 +227,11 @@ int am_gating_losses(const float* wp, const float* twp, int B, int T, const floa
 int am_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels, const float* tgt_boxes,
                   const int32_t* n_tgt, int B, int Q, int C, int Nmax, float w_class, float w_bbox, float w_giou,
                   float* cost, am_stream_t stream);
+/* am_match_cost for boxes of D numbers (hungarian_matcher.py:47-68): D = 4 as above; D = 7 = [cx,cy,cz,w,l,h,yaw] with the
+ * L1 term over all seven and the axis-aligned BEV GIoU on (cx -+ w/2, cy -+ l/2); any other D: no GIoU term. */
+int am_match_cost_d(const float* logits, const float* boxes, int D, const int64_t* tgt_labels, const float* tgt_boxes,
+                    const int32_t* n_tgt, int B, int Q, int C, int Nmax, float w_class, float w_bbox, float w_giou,
+                    float* cost, am_stream_t stream);
 int am_lsap_batched(const float* cost, int B, int nr, const int32_t* nc_per, int nc_max, long long batch_stride,
                     long long row_stride, long long col_stride, int64_t* row_idx, int64_t* col_idx, int kmax,
                     int32_t* count, int32_t* status, am_stream_t stream);

@@ -94,15 +94,21 @@ def generalized_box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def cost_matrix(pred_logits: torch.Tensor, pred_boxes: torch.Tensor, tgt_labels: torch.Tensor,
                 tgt_boxes: torch.Tensor, cost_class: float = 1.0, cost_bbox: float = 5.0,
                 cost_giou: float = 2.0) -> torch.Tensor:
-    """One image: [Q,C] logits, [Q,4] cxcywh boxes, [Ni] labels, [Ni,4] cxcywh boxes -> [Q,Ni] fp32.
-    hungarian_matcher.py:36-75, D == 4 branch; summation order bbox, class, giou as at :73-75."""
+    """One image: [Q,C] logits, [Q,D] boxes, [Ni] labels, [Ni,D] boxes -> [Q,Ni] fp32.
+    hungarian_matcher.py:36-75 (D == 4 cxcywh, D == 7 BEV, other D without GIoU); summation order bbox, class, giou (:73-75)."""
     prob = pred_logits.softmax(-1)
     c_class = -prob[:, tgt_labels]
     c_bbox = torch.cdist(pred_boxes, tgt_boxes, p=1)
-    if cost_giou > 0:
+    D = pred_boxes.shape[1]
+    if cost_giou > 0 and D == 4:
         c_giou = -generalized_box_iou(box_cxcywh_to_xyxy(pred_boxes), box_cxcywh_to_xyxy(tgt_boxes))
+    elif cost_giou > 0 and D == 7:
+        # hungarian_matcher.py:52-66: [cx, cy, cz, w, l, h, yaw] -> axis-aligned BEV box (cx -+ w/2, cy -+ l/2)
+        def bev(b):
+            return torch.stack([b[:, 0] - b[:, 3] / 2, b[:, 1] - b[:, 4] / 2, b[:, 0] + b[:, 3] / 2, b[:, 1] + b[:, 4] / 2], dim=1)
+        c_giou = -generalized_box_iou(bev(pred_boxes), bev(tgt_boxes))
     else:
-        c_giou = torch.zeros_like(c_bbox)
+        c_giou = torch.zeros_like(c_bbox)  # hungarian_matcher.py:67-70
     return cost_bbox * c_bbox + cost_class * c_class + cost_giou * c_giou
 
 

@@ -110,8 +110,41 @@ class BDDDrivableExpert(_DenseExpert):
         super().__init__(num_classes, pretrained_backbone)
 
 
+class NuScenesExpert(nn.Module):
+    """models/experts/nuscenes_expert.py:96-190, image branch (use_lidar=False, the AutoMoE configuration): resnet18
+    children()[:-1] (trunk + AdaptiveAvgPool2d(1)) -> Linear(512,256) -> + query embeddings -> decoder -> heads."""
+
+    def __init__(self, image_backbone=None, lidar_backbone=None, fusion: str = "concat", num_queries: int = 100,
+                 use_lidar: bool = False, use_tnet: bool = False, bbox_dim: int = 7, pretrained_backbone: bool = True):
+        super().__init__()
+        assert not use_lidar and lidar_backbone is None, "LiDAR branch not restated"
+        if image_backbone is None:
+            _no_pretrained(pretrained_backbone)
+            trunk = resnet18_trunk()
+            trunk.append(nn.AdaptiveAvgPool2d((1, 1)))
+            self.image_backbone = trunk
+            self.image_projection = nn.Linear(512, 256)
+        else:
+            self.image_backbone = image_backbone
+            self.image_projection = nn.Identity()
+        self.num_queries, self.bbox_dim = num_queries, bbox_dim
+        self.query_embed = nn.Embedding(num_queries, 256)
+        self.decoder = nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Dropout(0.3), nn.Linear(256, 128), nn.ReLU(),
+                                     nn.Dropout(0.3))
+        self.class_head = nn.Linear(128, 10)
+        self.bbox_head = nn.Linear(128, bbox_dim)
+
+    def forward(self, batch):
+        f = self.image_backbone(batch["image"])
+        f = self.image_projection(f.view(f.size(0), -1))
+        B = f.size(0)
+        x = f.unsqueeze(1).expand(B, self.num_queries, -1) + self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
+        x = self.decoder(x)
+        return {"class_logits": self.class_head(x), "bbox_preds": self.bbox_head(x)}
+
+
 # --------------------------------------------------------------------------------------------
-# Extractors: models/experts/expert_extractors.py:20-106, 140-200
+# Extractors: models/experts/expert_extractors.py:20-137, 140-200
 # --------------------------------------------------------------------------------------------
 def _extractor_mlp(cin: int, out_dim: int) -> nn.Sequential:
     # indices 0 pool, 1 flatten, 2 linear, 3 relu, 4 dropout, 5 linear, 6 layernorm
@@ -144,6 +177,20 @@ class DrivableExpertExtractor(SegmentationExpertExtractor):
         super().__init__(output_dim, num_classes)
 
 
+class NuScenesExpertExtractor(nn.Module):
+    """expert_extractors.py:108-137."""
+
+    def __init__(self, output_dim: int = 256, num_queries: int = 100, num_classes: int = 10, bbox_dim: int = 7):
+        super().__init__()
+        self.output_dim, self.num_queries, self.num_classes, self.bbox_dim = output_dim, num_queries, num_classes, bbox_dim
+        self.feature_extractor = nn.Sequential(nn.Linear(num_queries * (num_classes + bbox_dim), 512), nn.ReLU(), nn.Dropout(0.1),
+                                               nn.Linear(512, output_dim), nn.LayerNorm(output_dim))
+
+    def forward(self, o):
+        c = torch.cat([o["class_logits"], o["bbox_preds"]], dim=-1)
+        return self.feature_extractor(c.view(c.size(0), -1))
+
+
 class ExpertOutputManager(nn.Module):
     def __init__(self, extractors):
         super().__init__()
@@ -158,6 +205,10 @@ def create_expert_extractors(expert_configs: List[Dict]) -> ExpertOutputManager:
              "drivable": (DrivableExpertExtractor, 3)}
     ex = []
     for c in expert_configs:
+        if c["type"] == "nuscenes":
+            ex.append(NuScenesExpertExtractor(output_dim=c.get("output_dim", 256), num_queries=c.get("num_queries", 100),
+                                              num_classes=c.get("num_classes", 10), bbox_dim=c.get("bbox_dim", 7)))
+            continue
         if c["type"] not in table:
             raise ValueError(f"Unknown expert type: {c['type']}")
         cls, ncls = table[c["type"]]
@@ -324,6 +375,12 @@ class AutoMoE(nn.Module):
         self.context_config, self.policy_config = context_config, policy_config
         self.experts = nn.ModuleList()
         for c in expert_configs:
+            if c["type"] == "nuscenes":  # automoe.py:63-70
+                self.experts.append(NuScenesExpert(num_queries=c.get("num_queries", 100), fusion=c.get("fusion", "concat"),
+                                                   use_lidar=c.get("use_lidar", False), use_tnet=c.get("use_tnet", False),
+                                                   bbox_dim=c.get("bbox_dim", 7),
+                                                   pretrained_backbone=c.get("pretrained_backbone", True)))
+                continue
             if c["type"] not in _EXPERTS:
                 raise ValueError(f"Unknown expert type: {c['type']}")
             cls, ncls = _EXPERTS[c["type"]]
@@ -355,7 +412,8 @@ class AutoMoE(nn.Module):
 
     def forward(self, batch):
         ctx = self._context(batch)
-        outs = [e(batch["image"]) for e in self.experts]
+        outs = [e({"image": batch["image"], "lidar": batch.get("lidar")}) if isinstance(e, NuScenesExpert) else e(batch["image"])
+                for e in self.experts]  # automoe.py:156-187
         feats = self.expert_extractors.extract_features(outs)
         g = self.gating_network(feats, ctx)
         p = self.policy_head(batch["image"], context=g["combined_output"])

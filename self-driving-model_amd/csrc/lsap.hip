@@ -13,31 +13,39 @@
 
 namespace {
 
+// D = 4: boxes are cxcywh, 2-D GIoU.  D = 7: [cx, cy, cz, w, l, h, yaw] -- the L1 term runs over all seven numbers, the
+// GIoU term is the reference's axis-aligned BEV approximation on (cx -+ w/2, cy -+ l/2) (hungarian_matcher.py:52-66).
+// Any other D: L1 + class only (GIoU term zero, hungarian_matcher.py:67-68).
+template <int D>
 __global__ __launch_bounds__(256) void match_cost_k(const float* __restrict__ logits, const float* __restrict__ boxes,
                                                     const long long* __restrict__ tgt_labels, const float* __restrict__ tgt_boxes,
-                                                    const int* __restrict__ n_tgt, int Q, int C, int Nmax, float w_class,
+                                                    const int* __restrict__ n_tgt, int Q, int C, int Nmax, int Dr, float w_class,
                                                     float w_bbox, float w_giou, float* __restrict__ cost) {
   const int b = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
+  const int dd = D > 0 ? D : Dr;
   const int ni = n_tgt[b];
   const float* lg = logits + ((size_t)b * Q + q) * C;
   float mx = -INFINITY;
   for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[c]);
   float se = 0.f;
   for (int c = 0; c < C; ++c) se += expf(lg[c] - mx);
-  const float* pb = boxes + ((size_t)b * Q + q) * 4;
-  const float pcx = pb[0], pcy = pb[1], pw = pb[2], ph = pb[3];
+  const float* pb = boxes + ((size_t)b * Q + q) * dd;
+  constexpr bool HAS_GIOU = D == 4 || D == 7;
+  // the two box extents the GIoU term uses: (w, h) for D = 4, (w, l) for D = 7
+  const float pcx = pb[0], pcy = pb[1], pw = HAS_GIOU ? pb[D == 4 ? 2 : 3] : 0.f, ph = HAS_GIOU ? pb[D == 4 ? 3 : 4] : 0.f;
   const float px1 = pcx - 0.5f * pw, py1 = pcy - 0.5f * ph, px2 = pcx + 0.5f * pw, py2 = pcy + 0.5f * ph;
   const float parea = (px2 - px1) * (py2 - py1);
   for (int j = 0; j < ni; ++j) {
     const long long lab = tgt_labels[(size_t)b * Nmax + j];
     const float prob = (lab >= 0 && lab < C) ? expf(lg[lab] - mx) / se : 0.f;
-    const float* tb = tgt_boxes + ((size_t)b * Nmax + j) * 4;
-    const float tcx = tb[0], tcy = tb[1], tw = tb[2], th = tb[3];
-    const float l1 = ((fabsf(pcx - tcx) + fabsf(pcy - tcy)) + fabsf(pw - tw)) + fabsf(ph - th);
+    const float* tb = tgt_boxes + ((size_t)b * Nmax + j) * dd;
+    float l1 = 0.f;
+    for (int k = 0; k < dd; ++k) l1 += fabsf(pb[k] - tb[k]);  // torch.cdist(p=1): sum over the box dimension in order
     float giou = 0.f;
-    if (w_giou > 0.f) {
+    if (HAS_GIOU && w_giou > 0.f) {
+      const float tcx = tb[0], tcy = tb[1], tw = tb[D == 4 ? 2 : 3], th = tb[D == 4 ? 3 : 4];
       const float tx1 = tcx - 0.5f * tw, ty1 = tcy - 0.5f * th, tx2 = tcx + 0.5f * tw, ty2 = tcy + 0.5f * th;
       const float tarea = (tx2 - tx1) * (ty2 - ty1);
       const float iw = fmaxf(fminf(px2, tx2) - fmaxf(px1, tx1), 0.f), ih = fmaxf(fminf(py2, ty2) - fmaxf(py1, ty1), 0.f);
@@ -212,16 +220,27 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
 
 }  // namespace
 
+extern "C" int am_match_cost_d(const float* logits, const float* boxes, int D, const int64_t* tgt_labels, const float* tgt_boxes,
+                               const int32_t* n_tgt, int B, int Q, int C, int Nmax, float w_class, float w_bbox, float w_giou,
+                               float* cost, am_stream_t stream) {
+  if (!logits || !boxes || !n_tgt || !cost || B < 0 || Q <= 0 || C <= 0 || Nmax < 0 || D <= 0) return AM_ERR_ARG;
+  if (Nmax > 0 && (!tgt_labels || !tgt_boxes)) return AM_ERR_ARG;
+  if (B == 0 || Nmax == 0) return AM_OK;
+  const dim3 grid(am_cdiv(Q, 256), B);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define AM_MC_ARGS logits, boxes, (const long long*)tgt_labels, tgt_boxes, (const int*)n_tgt, Q, C, Nmax, D, w_class, w_bbox, w_giou, cost
+  if (D == 4) hipLaunchKernelGGL(match_cost_k<4>, grid, dim3(256), 0, s, AM_MC_ARGS);
+  else if (D == 7) hipLaunchKernelGGL(match_cost_k<7>, grid, dim3(256), 0, s, AM_MC_ARGS);
+  else hipLaunchKernelGGL(match_cost_k<0>, grid, dim3(256), 0, s, AM_MC_ARGS);
+#undef AM_MC_ARGS
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
 extern "C" int am_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels, const float* tgt_boxes,
                              const int32_t* n_tgt, int B, int Q, int C, int Nmax, float w_class, float w_bbox, float w_giou,
                              float* cost, am_stream_t stream) {
-  if (!logits || !boxes || !n_tgt || !cost || B < 0 || Q <= 0 || C <= 0 || Nmax < 0) return AM_ERR_ARG;
-  if (Nmax > 0 && (!tgt_labels || !tgt_boxes)) return AM_ERR_ARG;
-  if (B == 0 || Nmax == 0) return AM_OK;
-  hipLaunchKernelGGL(match_cost_k, dim3(am_cdiv(Q, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream), logits, boxes,
-                     (const long long*)tgt_labels, tgt_boxes, (const int*)n_tgt, Q, C, Nmax, w_class, w_bbox, w_giou, cost);
-  AM_CHECK_LAUNCH();
-  return AM_OK;
+  return am_match_cost_d(logits, boxes, 4, tgt_labels, tgt_boxes, n_tgt, B, Q, C, Nmax, w_class, w_bbox, w_giou, cost, stream);
 }
 
 extern "C" int am_lsap_batched(const float* cost, int B, int nr, const int32_t* nc_per, int nc_max, long long batch_stride,

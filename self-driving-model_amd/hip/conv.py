@@ -104,9 +104,9 @@ class ConvSpec:
 
 
 def channel_ld(c: int, es: int) -> int:
-    """Pixel stride (elements) of a C-channel NHWC activation: C itself when rows are 16-byte multiples,
-    else padded to a 64-byte multiple (expert heads with 14 / 19 / 3 channels)."""
-    return c if (c * es) % 16 == 0 else ((c * es + 63) // 64) * 64 // es
+    """Pixel stride (elements) of a C-channel NHWC activation: C itself when rows are 64-byte multiples (the gather
+    run of the input-gradient GEMM), else padded to the next 64-byte multiple (heads with 14 / 19 / 3 / 10 / 7 / 4 channels)."""
+    return c if (c * es) % 64 == 0 else ((c * es + 63) // 64) * 64 // es
 
 
 def out_size(n: int, s: ConvSpec) -> int:

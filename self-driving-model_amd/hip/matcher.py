@@ -44,15 +44,17 @@ def lsap_batched(cost: torch.Tensor, n_cols: Optional[torch.Tensor] = None, tran
 
 def match_cost(pred_logits: torch.Tensor, pred_boxes: torch.Tensor, tgt_labels: torch.Tensor, tgt_boxes: torch.Tensor,
                n_tgt: torch.Tensor, w_class: float, w_bbox: float, w_giou: float) -> torch.Tensor:
-    """pred_logits [B,Q,C], pred_boxes [B,Q,4] cxcywh, tgt_labels [B,Nmax] int64, tgt_boxes [B,Nmax,4] cxcywh,
-    n_tgt [B] int32 -> cost [B,Nmax,Q] fp32 (transposed storage: cost[b, j, q])."""
+    """pred_logits [B,Q,C], pred_boxes [B,Q,D], tgt_labels [B,Nmax] int64, tgt_boxes [B,Nmax,D], n_tgt [B] int32 ->
+    cost [B,Nmax,Q] fp32 (transposed storage: cost[b, j, q]).  D = 4: cxcywh + GIoU; D = 7: BEV GIoU; else no GIoU term."""
     require_hip(pred_logits, "pred_logits")
     pl = pred_logits.detach().float().contiguous()
     pb = pred_boxes.detach().float().contiguous()
     B, Q, C = pl.shape
+    D = pb.shape[2]
     Nmax = tgt_labels.shape[1]
     cost = torch.zeros((B, max(Nmax, 1), Q), dtype=torch.float32, device=pl.device)
     if Nmax > 0:
-        _L().am_match_cost(ptr(pl), ptr(pb), ptr(tgt_labels.contiguous()), ptr(tgt_boxes.float().contiguous()),
-                           ptr(n_tgt.contiguous()), B, Q, C, Nmax, float(w_class), float(w_bbox), float(w_giou), ptr(cost), stream())
+        assert tgt_boxes.shape[2] == D, "prediction and target boxes must have the same number of box parameters"
+        _L().am_match_cost_d(ptr(pl), ptr(pb), D, ptr(tgt_labels.contiguous()), ptr(tgt_boxes.float().contiguous()),
+                             ptr(n_tgt.contiguous()), B, Q, C, Nmax, float(w_class), float(w_bbox), float(w_giou), ptr(cost), stream())
     return cost

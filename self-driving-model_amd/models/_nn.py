@@ -45,6 +45,27 @@ class Linear(nn.Linear):
         return hops.LinearAct.apply(x, self.weight, self.bias, relu)
 
 
+class RowLinear(nn.Linear):
+    """nn.Linear applied to MANY rows (B*Q query rows of the NuScenes decoder, models/experts/nuscenes_expert.py:139-150).
+    The batch-sized GEMV kernels behind `Linear` re-read the weight per 8 rows; this one runs the rows through the
+    gather-GEMM as a 1x1 convolution over an NHWC view [1, rows, 1, K] in fp32 (exact-fp32 MFMA path), with bias (+ReLU)
+    in the epilogue, and the conv dgrad / wgrad kernels in backward.  Parameters keep nn.Linear's names and shapes."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__(cin, cout)
+        assert (cin * 4) % 64 == 0, "RowLinear needs K to be a multiple of 16 floats (64-byte gather runs)"
+        self.spec = hconv.ConvSpec(cin, cout, 1, 1, 0)
+        self._packed = hconv.PackedWeights()
+
+    def forward(self, x, relu: bool = False):
+        lead = x.shape[:-1]
+        rows = x.reshape(1, -1, 1, self.in_features).float().contiguous()
+        cfg = hconv._Cfg(self.spec, self._packed, None, relu, 1.0)  # fp32 rows: no loss scaling inside
+        y = hconv.conv_bn_act(rows, self.weight.view(self.out_features, self.in_features, 1, 1), self.bias, None, relu, None, cfg,
+                              False)
+        return y[..., : self.out_features].reshape(*lead, self.out_features)
+
+
 class ReLU(nn.ReLU):
     """Placeholder kept for state_dict index parity; MLPSequential fuses it into the preceding Linear."""
 

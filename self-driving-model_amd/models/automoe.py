@@ -19,7 +19,7 @@ from .. import runtime
 from ..hip import conv as hconv
 from ..hip import ops as hops
 from .context.context_features import create_context_extractor
-from .experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
+from .experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert, NuScenesExpert
 from .experts.expert_extractors import create_expert_extractors
 from .gating.gating_network import GatingNetwork
 from .policy.trajectory_head import TrajectoryPolicy
@@ -69,8 +69,10 @@ class AutoMoE(nn.Module):
                 e = BDDDrivableExpert(num_classes=config.get("num_classes", 3),
                                       pretrained_backbone=config.get("pretrained_backbone", True))
             elif t == "nuscenes":
-                raise ValueError("Unknown expert type: nuscenes (NuScenesExpert hard-codes a pretrained fetch in the "
-                                 "reference and is outside this build's hot-path scope; see DESIGN.md)")
+                e = NuScenesExpert(num_queries=config.get("num_queries", 100), fusion=config.get("fusion", "concat"),
+                                   use_lidar=config.get("use_lidar", False), use_tnet=config.get("use_tnet", False),
+                                   bbox_dim=config.get("bbox_dim", 7),
+                                   pretrained_backbone=config.get("pretrained_backbone", True))  # reference: always pretrained
             else:
                 raise ValueError(f"Unknown expert type: {t}")
             experts.append(e)
@@ -109,7 +111,10 @@ class AutoMoE(nn.Module):
         outs = []
         for i, expert in enumerate(self.experts):
             try:
-                outs.append(expert(batch["image"], nhwc_input=nhwc))
+                if self.expert_configs[i]["type"] == "nuscenes":
+                    outs.append(expert({"image": batch["image"], "lidar": batch.get("lidar")}, nhwc_input=nhwc))
+                else:
+                    outs.append(expert(batch["image"], nhwc_input=nhwc))
             except Exception as e:  # noqa: BLE001
                 warnings.warn(f"Error running expert {i} ({self.expert_configs[i]['type']}): {e}")
                 if os.environ.get("AUTOMOE_SWALLOW_EXPERT_ERRORS", "0") != "1":
@@ -126,7 +131,10 @@ class AutoMoE(nn.Module):
                 feats.append(extractor.feature_extractor(pooled, start=2))  # skip pool + flatten
                 outs.append(low.detach()[..., : expert.num_classes].permute(0, 3, 1, 2))
             else:
-                out = expert(batch["image"], nhwc_input=nhwc)
+                if self.expert_configs[i]["type"] == "nuscenes":
+                    out = expert({"image": batch["image"], "lidar": batch.get("lidar")}, nhwc_input=nhwc)
+                else:
+                    out = expert(batch["image"], nhwc_input=nhwc)
                 outs.append(out)
                 feats.append(extractor(out))
         return outs, feats

@@ -1,8 +1,9 @@
 from .bdd_detection_expert import BDDDetectionExpert
 from .bdd_drivable_expert import BDDDrivableExpert
 from .bdd_segmentation_expert import BDDSegmentationExpert
-from .expert_extractors import (DetectionExpertExtractor, DrivableExpertExtractor, SegmentationExpertExtractor,
-                                create_expert_extractors)
+from .nuscenes_expert import NuScenesExpert
+from .expert_extractors import (DetectionExpertExtractor, DrivableExpertExtractor, NuScenesExpertExtractor,
+                                SegmentationExpertExtractor, create_expert_extractors)
 
-__all__ = ["BDDDetectionExpert", "BDDDrivableExpert", "BDDSegmentationExpert", "DetectionExpertExtractor",
-           "SegmentationExpertExtractor", "DrivableExpertExtractor", "create_expert_extractors"]
+__all__ = ["BDDDetectionExpert", "BDDDrivableExpert", "BDDSegmentationExpert", "NuScenesExpert", "DetectionExpertExtractor",
+           "SegmentationExpertExtractor", "DrivableExpertExtractor", "NuScenesExpertExtractor", "create_expert_extractors"]

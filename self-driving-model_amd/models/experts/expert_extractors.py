@@ -1,5 +1,4 @@
-"""Expert output extractors -- drop-in for models/experts/expert_extractors.py:5-106,140-200
-(the nuScenes extractor belongs to the out-of-scope 4th expert)."""
+"""Expert output extractors -- drop-in for models/experts/expert_extractors.py:5-200."""
 from typing import Dict, List
 
 import torch
@@ -49,6 +48,20 @@ class DrivableExpertExtractor(SegmentationExpertExtractor):
         super().__init__(output_dim, num_classes)
 
 
+class NuScenesExpertExtractor(ExpertOutputExtractor):
+    """expert_extractors.py:108-137: cat(class_logits, bbox_preds) over the query axis -> flatten -> MLP -> LayerNorm."""
+
+    def __init__(self, output_dim: int = 256, num_queries: int = 100, num_classes: int = 10, bbox_dim: int = 7):
+        super().__init__(output_dim)
+        self.num_queries, self.num_classes, self.bbox_dim = num_queries, num_classes, bbox_dim
+        self.feature_extractor = MLPSequential(Linear(num_queries * (num_classes + bbox_dim), 512), ReLU(), Dropout(0.1),
+                                               Linear(512, output_dim), LayerNorm(output_dim))
+
+    def forward(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
+        combined = torch.cat([expert_output["class_logits"], expert_output["bbox_preds"]], dim=-1)
+        return self.feature_extractor(combined.view(combined.size(0), -1))
+
+
 class ExpertOutputManager(nn.Module):
     def __init__(self, extractors: List[ExpertOutputExtractor]):
         super().__init__()
@@ -65,8 +78,9 @@ def create_expert_extractors(expert_configs: List[Dict]) -> ExpertOutputManager:
     for config in expert_configs:
         t = config["type"]
         if t == "nuscenes":
-            raise ValueError("Unknown expert type: nuscenes (the 4th expert is outside this build's hot-path scope; "
-                             "see DESIGN.md)")
+            extractors.append(NuScenesExpertExtractor(output_dim=config.get("output_dim", 256), num_queries=config.get("num_queries", 100),
+                                                      num_classes=config.get("num_classes", 10), bbox_dim=config.get("bbox_dim", 7)))
+            continue
         if t not in table:
             raise ValueError(f"Unknown expert type: {t}")
         cls, ncls = table[t]

@@ -1,4 +1,4 @@
-"""HungarianMatcher -- drop-in for training/hungarian_matcher.py:13-85 (2-D boxes, D == 4).
+"""HungarianMatcher -- drop-in for training/hungarian_matcher.py:13-85 (D == 4 boxes, D == 7 BEV boxes, other D without GIoU).
 
 The reference computes one cost matrix per image on the GPU, copies it to the host and calls
 scipy.optimize.linear_sum_assignment (B device->host syncs per step).  Here the batched cost kernel and
@@ -24,10 +24,8 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def match_padded(self, pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt):
-        """Padded targets ([B,Nmax] labels, [B,Nmax,4] cxcywh boxes, [B] counts) -> device tensors
+        """Padded targets ([B,Nmax] labels, [B,Nmax,D] boxes, [B] counts) -> device tensors
         (pred_idx [B,k], tgt_idx [B,k], count [B], status [B]); no host synchronisation."""
-        if pred_boxes.shape[-1] != 4:
-            raise NotImplementedError("only 4-dim (cx,cy,w,h) boxes are on the accelerated path")
         cost = hm.match_cost(pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt, self.cost_class, self.cost_bbox,
                              self.cost_giou)
         return hm.lsap_batched(cost, n_tgt, transposed_storage=True)
@@ -40,7 +38,7 @@ class HungarianMatcher(nn.Module):
         counts = [int(t["labels"].shape[0]) for t in targets]
         nmax = max(counts) if counts else 0
         labels = torch.full((B, max(nmax, 1)), -1, dtype=torch.int64, device=dev)
-        boxes = torch.zeros((B, max(nmax, 1), 4), dtype=torch.float32, device=dev)
+        boxes = torch.zeros((B, max(nmax, 1), pred_boxes.shape[-1]), dtype=torch.float32, device=dev)
         for b, t in enumerate(targets):
             if counts[b]:
                 labels[b, : counts[b]] = t["labels"].to(dev)

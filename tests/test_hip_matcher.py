@@ -179,3 +179,31 @@ def test_detection_set_loss_vs_oracle():
     t2, c2, b2, _ = detection_set_loss({"class_logits": logits[:2].to(dev), "bbox_deltas": deltas[:2].to(dev)}, empty_b.to(dev),
                                        empty_l.to(dev), C, HungarianMatcher())
     assert float(b2) == 0.0 and torch.isnan(c2)
+
+
+@pytest.mark.parametrize("D", [7, 5, 4])
+def test_matcher_box_dimensions_vs_reference_golden(golden_dir, D):
+    """Device cost kernel + batched LSAP for D = 7 (BEV GIoU branch), D = 5 (no GIoU term), D = 4 against the reference
+    HungarianMatcher.forward compiled from source (tests/golden/make_golden_nuscenes.py): the cost matrices it handed to
+    scipy (fp32 tolerance) and the index pairs (exact), ragged target counts incl. an image without targets."""
+    from self_driving_model_amd.hip import matcher as hm
+    from self_driving_model_amd.training.hungarian_matcher import HungarianMatcher
+    g = np.load(os.path.join(golden_dir, "matcher_dims.npz"))
+    dev = _dev()
+    logits, boxes = torch.from_numpy(g[f"d{D}/logits"]).to(dev), torch.from_numpy(g[f"d{D}/boxes"]).to(dev)
+    targets = [{"boxes": torch.from_numpy(g[f"d{D}/tgt_boxes{b}"]).to(dev), "labels": torch.from_numpy(g[f"d{D}/tgt_labels{b}"]).to(dev)}
+               for b in range(3)]
+    counts = [int(t["labels"].numel()) for t in targets]
+    nmax = max(counts)
+    labels = torch.full((3, nmax), -1, dtype=torch.int64, device=dev)
+    tb = torch.zeros((3, nmax, D), device=dev)
+    for b, n in enumerate(counts):
+        if n:
+            labels[b, :n], tb[b, :n] = targets[b]["labels"], targets[b]["boxes"]
+    cost = hm.match_cost(logits, boxes, labels, tb, torch.tensor(counts, dtype=torch.int32, device=dev), 1.0, 5.0, 2.0)
+    for b, n in enumerate(counts):
+        if n:
+            np.testing.assert_allclose(cost[b, :n].t().cpu().numpy(), g[f"d{D}/cost{b}"], rtol=1e-4, atol=1e-5)
+    idx = HungarianMatcher(1.0, 5.0, 2.0)({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    for b in range(3):
+        assert np.array_equal(idx[b][0].cpu().numpy(), g[f"d{D}/rows{b}"]) and np.array_equal(idx[b][1].cpu().numpy(), g[f"d{D}/cols{b}"])

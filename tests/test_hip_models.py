@@ -568,3 +568,120 @@ def test_data_parallel_train_step_two_ranks_graph_and_eager(tmp_path):
     assert res["eager"]["losses"][-1] < res["eager"]["losses"][0]
     np.testing.assert_allclose(res["graph"]["losses"], res["eager"]["losses"], rtol=2e-3, atol=1e-4)
     close(res["graph"]["flat"], res["eager"]["flat"], rtol=5e-3, atol=5e-4)
+
+
+# ---- NuScenes expert + extractor, 4-expert AutoMoE ----
+FOUR_EXPERT_CFG = {"experts": AUTOMOE_CFG["experts"] + [{"type": "nuscenes", "num_queries": 196, "num_classes": 10, "output_dim": 256,
+                                                         "fusion": "sum", "use_lidar": False, "use_tnet": False, "bbox_dim": 4,
+                                                         "pretrained_backbone": False}],
+                   "gating": dict(AUTOMOE_CFG["gating"], top_k=2, noise_type="gumbel", noise_scale=0.0, apply_topk_at_eval=True),
+                   "context": AUTOMOE_CFG["context"], "policy": {"hidden_dim": 256, "num_waypoints": 10, "waypoint_dim": 2}}
+
+
+def _golden_param_grads(m, g, tag):
+    for n, p in m.named_parameters():
+        l2 = float(g[f"{tag}/gl2/{n}"])
+        close(p.grad.double().sum(), g[f"{tag}/gsum/{n}"], rtol=1e-3, atol=1e-4 * (1 + l2 * p.numel() ** 0.5), what=n)
+        close(p.grad.double().pow(2).sum().sqrt(), g[f"{tag}/gl2/{n}"], rtol=1e-3, atol=1e-5, what=n)
+
+
+def test_nuscenes_extractor_and_head_vs_reference_golden(golden_dir):
+    """HIP NuScenesExpertExtractor vs the reference module's outputs/gradients; HIP NuScenesExpert decoder + heads (fp32
+    gather-GEMM rows) vs the reference class compiled from source with a caller-supplied backbone."""
+    import self_driving_model_amd.models.experts as hx
+    g = np.load(os.path.join(golden_dir, "nuscenes.npz"))
+    dev = _dev()
+    for D in (4, 7):
+        m = seed_module_(hx.NuScenesExpertExtractor(256, num_queries=12, num_classes=10, bbox_dim=D), 700 + D).eval().to(dev)
+        cl, bb = seeded_tensor((3, 12, 10), 710 + D).to(dev).requires_grad_(), seeded_tensor((3, 12, D), 720 + D).to(dev).requires_grad_()
+        y = m({"class_logits": cl, "bbox_preds": bb})
+        (y * seeded_tensor((3, 256), 730).to(dev)).sum().backward()
+        close(y, g[f"ext{D}/features"], rtol=1e-4)
+        close(cl.grad, g[f"ext{D}/d_cls"], rtol=1e-3, atol=1e-6)
+        close(bb.grad, g[f"ext{D}/d_box"], rtol=1e-3, atol=1e-6)
+        _golden_param_grads(m, g, f"ext{D}")
+    for D, Q in ((7, 12), (4, 196)):
+        m = seed_module_(hx.NuScenesExpert(image_backbone=torch.nn.Identity(), num_queries=Q, bbox_dim=D), 740 + D).eval().to(dev)
+        feat = seeded_tensor((3, 256), 750 + D).to(dev).requires_grad_()
+        o = m({"image": feat})
+        (o["class_logits"] * seeded_tensor((3, Q, 10), 760).to(dev)).sum().add((o["bbox_preds"] * seeded_tensor((3, Q, D), 761).to(dev)).sum()).backward()
+        assert o["class_logits"].shape == (3, Q, 10) and o["bbox_preds"].shape == (3, Q, D)
+        close(o["class_logits"], g[f"head{D}/class_logits"], rtol=1e-4)
+        close(o["bbox_preds"], g[f"head{D}/bbox_preds"], rtol=1e-4)
+        close(feat.grad, g[f"head{D}/d_feat"], rtol=1e-3, atol=1e-5)
+        _golden_param_grads(m, g, f"head{D}")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_nuscenes_expert_fp32_vs_oracle(train):
+    """Whole expert (ResNet-18 trunk + pool + projection + query decoder), forward and every gradient, fp32 mode."""
+    from self_driving_model_amd import runtime
+    hip, ref = _pair("NuScenesExpert", 71, num_queries=20, bbox_dim=7, pretrained_backbone=False)
+    hip.train(train); ref.train(train)
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = seeded_tensor((2, 3, 64, 96), 72)
+    pc, pb = seeded_tensor((2, 20, 10), 73), seeded_tensor((2, 20, 7), 74)
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    o_r = ref({"image": x})
+    ((o_r["class_logits"] * pc).sum() + (o_r["bbox_preds"] * pb).sum()).backward()
+
+    def truth():
+        o = ref64({"image": x.double()})
+        ((o["class_logits"] * pc.double()).sum() + (o["bbox_preds"] * pb.double()).sum()).backward()
+        return ref64
+    with runtime.precision(torch.float32):
+        o = hip({"image": x.to(_dev())})
+        ((o["class_logits"] * pc.to(_dev())).sum() + (o["bbox_preds"] * pb.to(_dev())).sum()).backward()
+    close(o["class_logits"], o_r["class_logits"], what="class_logits")
+    close(o["bbox_preds"], o_r["bbox_preds"], what="bbox_preds")
+    _grad_check(hip, ref, RT, 2e-4, truth=truth)
+    with pytest.raises(NotImplementedError):
+        type(hip)(use_lidar=True, pretrained_backbone=False)
+
+
+def test_four_expert_automoe_train_step_fp32_vs_oracle():
+    """The reference's 4-expert model_config.json (pretrained fetch off): strict state_dict exchange with the oracle, one
+    frozen-expert train step in fp32, outputs / losses / gradients / BN buffers against the oracle."""
+    from oracle import torch_ref as oref
+    from oracle.losses import gating_losses
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training.train_gating_network import fused_gating_losses
+    ref = seed_module_(oref.create_automoe_model(FOUR_EXPERT_CFG, "cpu"), 80)
+    hip = create_automoe_model(FOUR_EXPERT_CFG, "cpu")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(_dev())
+    hip.freeze_experts(); ref.freeze_experts()
+    hip.train(); ref.train()
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = _batch(2, 64, 96, 90)
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    o_r = ref(batch)
+    l_r = gating_losses(o_r, batch["waypoints"], batch["speed"], {})
+    l_r["total_loss"].backward()
+
+    def truth():
+        b64 = {k: v.double() for k, v in batch.items()}
+        gating_losses(ref64(b64), b64["waypoints"], b64["speed"], {})["total_loss"].backward()
+        return ref64
+    with runtime.precision(torch.float32):
+        db = {k: v.to(_dev()) for k, v in batch.items()}
+        hip.fuse_expert_pooling = True
+        o = hip(db)
+        l = fused_gating_losses(o, db["waypoints"], db["speed"], {})
+        l["total_loss"].backward()
+    assert o["expert_weights"].shape == (2, 4)
+    for k in ("waypoints", "speed", "expert_weights", "context_features", "combined_features", "gate_logits"):
+        close(o[k], o_r[k], what=k)
+    close(o["expert_outputs"][3]["class_logits"], o_r["expert_outputs"][3]["class_logits"], what="nuscenes logits")
+    for k in l_r:
+        close(l[k], l_r[k], rtol=1e-4, atol=1e-6, what=k)
+    _grad_check(hip, ref, RT, 2e-4, truth=truth)
+    for (n, b), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
+        close(b.float(), br.float(), rtol=RT, atol=1e-5, what=n)

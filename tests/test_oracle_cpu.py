@@ -237,3 +237,75 @@ def test_automoe_oracle_shapes_and_invariants():
     assert n_train == 415_488 + 2_400 + 602_115 + 1_850_654
     with pytest.raises(ValueError):
         oref.create_automoe_model(dict(cfg, experts=[{"type": "lidar"}]), "cpu")
+
+
+# ---- NuScenes expert head / extractor, matcher box dimensions ----
+def _check_param_grads(m, g, tag):
+    for n, p in m.named_parameters():
+        l2 = float(g[f"{tag}/gl2/{n}"])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        np.testing.assert_allclose(got.double().sum().numpy(), g[f"{tag}/gsum/{n}"], rtol=1e-4, atol=1e-5 * (1 + l2 * p.numel() ** 0.5), err_msg=n)
+        np.testing.assert_allclose(got.double().pow(2).sum().sqrt().numpy(), g[f"{tag}/gl2/{n}"], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+def test_nuscenes_extractor_and_head_match_reference(golden_dir):
+    """oracle NuScenesExpertExtractor vs the reference module; oracle NuScenesExpert decoder + heads vs the reference class
+    compiled from source with a caller-supplied image backbone (tests/golden/make_golden_nuscenes.py)."""
+    g = _load(golden_dir, "nuscenes")
+    for D in (4, 7):
+        m = seed_module_(oref.NuScenesExpertExtractor(256, num_queries=12, num_classes=10, bbox_dim=D), 700 + D).eval()
+        cl, bb = seeded_tensor((3, 12, 10), 710 + D).requires_grad_(), seeded_tensor((3, 12, D), 720 + D).requires_grad_()
+        y = m({"class_logits": cl, "bbox_preds": bb})
+        (y * seeded_tensor((3, 256), 730)).sum().backward()
+        np.testing.assert_allclose(y.detach().numpy(), g[f"ext{D}/features"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(cl.grad.numpy(), g[f"ext{D}/d_cls"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(bb.grad.numpy(), g[f"ext{D}/d_box"], rtol=1e-4, atol=1e-7)
+        _check_param_grads(m, g, f"ext{D}")
+    for D, Q in ((7, 12), (4, 196)):
+        m = seed_module_(oref.NuScenesExpert(image_backbone=torch.nn.Identity(), num_queries=Q, bbox_dim=D), 740 + D).eval()
+        feat = seeded_tensor((3, 256), 750 + D).requires_grad_()
+        o = m({"image": feat})
+        (o["class_logits"] * seeded_tensor((3, Q, 10), 760)).sum().add((o["bbox_preds"] * seeded_tensor((3, Q, D), 761)).sum()).backward()
+        np.testing.assert_allclose(o["class_logits"].detach().numpy(), g[f"head{D}/class_logits"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o["bbox_preds"].detach().numpy(), g[f"head{D}/bbox_preds"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(feat.grad.numpy(), g[f"head{D}/d_feat"], rtol=1e-4, atol=1e-6)
+        _check_param_grads(m, g, f"head{D}")
+
+
+@pytest.mark.parametrize("D", [7, 5, 4])
+def test_matcher_box_dimensions_match_reference(golden_dir, D):
+    """oracle cost matrix + C LSAP vs the reference HungarianMatcher.forward compiled from source (D = 7 BEV branch,
+    D = 5 no-GIoU branch, D = 4): cost matrices as handed to scipy, and the indices it returned."""
+    g = _load(golden_dir, "matcher_dims")
+    logits, boxes = torch.from_numpy(g[f"d{D}/logits"]), torch.from_numpy(g[f"d{D}/boxes"])
+    targets = [{"boxes": torch.from_numpy(g[f"d{D}/tgt_boxes{b}"]), "labels": torch.from_numpy(g[f"d{D}/tgt_labels{b}"])} for b in range(3)]
+    for b in range(3):
+        C = omatcher.cost_matrix(logits[b], boxes[b], targets[b]["labels"], targets[b]["boxes"], 1.0, 5.0, 2.0).numpy()
+        np.testing.assert_allclose(C, g[f"d{D}/cost{b}"], rtol=1e-5, atol=1e-5)
+    idx = omatcher.HungarianMatcher(1.0, 5.0, 2.0)({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    for b in range(3):
+        np.testing.assert_array_equal(idx[b][0].numpy(), g[f"d{D}/rows{b}"])
+        np.testing.assert_array_equal(idx[b][1].numpy(), g[f"d{D}/cols{b}"])
+
+
+def test_four_expert_reference_config_oracle():
+    """The reference's own 4-expert model_config.json shape (with the pretrained fetch turned off): construction, keys,
+    one forward at a small size."""
+    cfg = {"experts": [{"type": "detection", "num_classes": 10, "output_dim": 256, "pretrained_backbone": False},
+                       {"type": "segmentation", "num_classes": 19, "output_dim": 256, "pretrained_backbone": False},
+                       {"type": "drivable", "num_classes": 3, "output_dim": 256, "pretrained_backbone": False},
+                       {"type": "nuscenes", "num_queries": 196, "num_classes": 10, "output_dim": 256, "fusion": "sum", "use_lidar": False,
+                        "use_tnet": False, "bbox_dim": 4, "pretrained_backbone": False}],
+           "gating": {"processed_dim": 256, "hidden_dim": 128, "temperature": 1.0, "use_softmax": True, "top_k": 2},
+           "context": {"type": "simple", "context_dim": 64}, "policy": {"hidden_dim": 256, "num_waypoints": 10, "waypoint_dim": 2}}
+    m = oref.create_automoe_model(cfg).eval()
+    assert sum(p.numel() for p in m.parameters()) == 53_109_940
+    sd = m.state_dict()
+    for k in ("experts.3.image_backbone.0.weight", "experts.3.image_projection.weight", "experts.3.query_embed.weight",
+              "experts.3.decoder.3.bias", "experts.3.class_head.weight", "experts.3.bbox_head.bias",
+              "expert_extractors.extractors.3.feature_extractor.0.weight", "expert_extractors.extractors.3.feature_extractor.4.bias"):
+        assert k in sd, k
+    with torch.no_grad():
+        o = m({"image": seeded_tensor((1, 3, 64, 96), 5), "speed": seeded_tensor((1, 10), 6)})
+    assert o["expert_weights"].shape == (1, 4) and abs(float(o["expert_weights"].sum()) - 1) < 1e-6
+    assert o["expert_outputs"][3]["class_logits"].shape == (1, 196, 10) and o["expert_outputs"][3]["bbox_preds"].shape == (1, 196, 4)
