@@ -5,6 +5,7 @@ torch-CPU fp32 restatement of the loss assembly on the hot path:
   segmentation_loss    training/train_bdd100k_ddp.py:58,188-194
   gating_losses        training/train_gating_network.py:21-74
   train_step           the step glue of train_bdd100k_ddp.py:89-100 / train_gating_network.py:92-105
+  policy_losses, carla_detection_loss, carla_sanitize_mask   train_carla_policy.py:22-30, train_carla_bdd_experts_ddp.py:71-140
 """
 from __future__ import annotations
 
@@ -87,3 +88,55 @@ def clip_and_step(params: List[torch.Tensor], optimizer: torch.optim.Optimizer, 
     norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
     optimizer.step()
     return norm
+
+
+# ---- the CARLA trainers' loss glue ----
+def policy_losses(pred: Dict[str, torch.Tensor], target_wp: torch.Tensor, target_spd: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """training/train_carla_policy.py:22-30."""
+    ade = F.l1_loss(pred["waypoints"], target_wp)
+    fde = F.l1_loss(pred["waypoints"][:, -1, :], target_wp[:, -1, :])
+    l_spd = F.l1_loss(pred["speed"], target_spd)
+    d = pred["waypoints"][:, 1:, :] - pred["waypoints"][:, :-1, :]
+    l_smooth = F.l1_loss(d[:, 1:, :], d[:, :-1, :])
+    return {"loss": ade + 2.0 * fde + 0.2 * l_spd + 0.1 * l_smooth, "ade": ade, "fde": fde, "speed": l_spd, "smooth": l_smooth}
+
+
+def carla_detection_loss(model_out: Dict[str, torch.Tensor], gt_boxes: torch.Tensor, gt_labels: torch.Tensor, num_classes: int,
+                         matcher: HungarianMatcher, bbox_loss_weight: float = 1.0):
+    """training/train_carla_bdd_experts_ddp.py:71-127: class loss = mean CE over the matched queries (0.0 without matches),
+    SmoothL1(mean) over the matched boxes, total = cls + bbox_loss_weight * box."""
+    logits, boxes = model_out["class_logits"], model_out["bbox_deltas"]
+    B, C, H, W = logits.shape
+    Q = H * W
+    logits = logits.permute(0, 2, 3, 1).reshape(B, Q, C)
+    boxes = boxes.permute(0, 2, 3, 1).reshape(B, Q, 4)
+    targets = []
+    for b in range(B):
+        keep = gt_labels[b] != -1
+        bx = gt_boxes[b][keep]
+        targets.append({"boxes": box_xyxy_to_cxcywh(bx) if bx.numel() > 0 else bx, "labels": gt_labels[b][keep]})
+    indices = matcher({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    tgt_cls = torch.full((B * Q,), num_classes, dtype=torch.int64)
+    tgt_box = torch.zeros((B * Q, 4), dtype=torch.float32)
+    for b, (pi, ti) in enumerate(indices):
+        if pi.numel() > 0:
+            tgt_cls[b * Q + pi] = targets[b]["labels"][ti]
+            tgt_box[b * Q + pi] = targets[b]["boxes"][ti]
+    valid = tgt_cls != num_classes
+    if valid.any():
+        cls_loss = F.cross_entropy(logits.reshape(B * Q, C)[valid], tgt_cls[valid], reduction="mean")
+        box_loss = F.smooth_l1_loss(boxes.reshape(B * Q, 4)[valid], tgt_box[valid], reduction="mean")
+    else:
+        cls_loss, box_loss = torch.tensor(0.0), torch.tensor(0.0)
+    return cls_loss + bbox_loss_weight * box_loss, cls_loss, box_loss, indices
+
+
+def carla_sanitize_mask(mask: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """training/train_carla_bdd_experts_ddp.py:132-138."""
+    if mask.dim() == 4:
+        mask = mask[..., 0]
+    invalid = (mask < 0) | (mask >= num_classes)
+    if invalid.any():
+        mask = mask.clone()
+        mask[invalid] = 255
+    return mask

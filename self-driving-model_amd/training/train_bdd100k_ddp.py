@@ -30,8 +30,11 @@ def box_xyxy_to_cxcywh(b: torch.Tensor) -> torch.Tensor:
     return torch.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], dim=-1)
 
 
-def detection_set_loss(outputs, gt_boxes, gt_labels, num_classes: int, matcher: HungarianMatcher, bbox_loss_weight: float = 2.0):
-    """train_bdd100k_ddp.py:117-186 without host synchronisation.
+def detection_set_loss(outputs, gt_boxes, gt_labels, num_classes: int, matcher: HungarianMatcher, bbox_loss_weight: float = 2.0,
+                       zero_when_unmatched: bool = False):
+    """train_bdd100k_ddp.py:117-186 without host synchronisation.  `zero_when_unmatched` selects the CARLA fine-tuning variant
+    (train_carla_bdd_experts_ddp.py:108-118): the class loss is the mean cross-entropy over the matched queries there as
+    well, but a batch without any match gives 0.0 instead of the NaN of a cross-entropy whose targets are all ignored.
     outputs: {'class_logits' [B,C,h,w], 'bbox_deltas' [B,4,h,w]}; gt_boxes [B,Nmax,4] xyxy padded with -1; gt_labels [B,Nmax]
     padded with -1 (padding is trailing, as detection_collate_fn produces).  Returns (total, class_loss, bbox_loss, match)."""
     logits, deltas = outputs["class_logits"], outputs["bbox_deltas"]
@@ -58,6 +61,8 @@ def detection_set_loss(outputs, gt_boxes, gt_labels, num_classes: int, matcher: 
     tgt_cls = torch.where(tgt_cls < 0, torch.full_like(tgt_cls, num_classes), tgt_cls)
     class_loss = hops.CrossEntropy2d.apply(logits.contiguous(), tgt_cls.view(B, h, w), num_classes)
     matched = (tgt_cls != num_classes)
+    if zero_when_unmatched:
+        class_loss = torch.where(matched.any(), class_loss, torch.zeros_like(class_loss))
     d = (pred_boxes.reshape(B * Q, 4) - tgt_box).abs()
     sl1 = torch.where(d < 1.0, 0.5 * d * d, d - 0.5) * matched[:, None]
     n_el = (matched.sum() * 4).clamp(min=1)

@@ -685,3 +685,76 @@ def test_four_expert_automoe_train_step_fp32_vs_oracle():
     _grad_check(hip, ref, RT, 2e-4, truth=truth)
     for (n, b), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
         close(b.float(), br.float(), rtol=RT, atol=1e-5, what=n)
+
+
+# ---- CARLA trainers ----
+def test_fused_policy_losses_vs_reference_golden(golden_dir):
+    """train_carla_policy's objective as one launch vs the reference function's values and gradients."""
+    from self_driving_model_amd.training.train_carla_policy import fused_losses
+    g = np.load(os.path.join(golden_dir, "policy_losses.npz"))
+    dev = _dev()
+    for tag, (B, T) in {"b6t8": (6, 8), "b32t10": (32, 10), "b3t3": (3, 3)}.items():
+        wp = seeded_tensor((B, T, 2), 900 + B).to(dev).requires_grad_()
+        spd = seeded_tensor((B, T), 901 + B).to(dev).requires_grad_()
+        r = fused_losses({"waypoints": wp, "speed": spd}, seeded_tensor((B, T, 2), 902 + B).to(dev), seeded_tensor((B, T), 903 + B).to(dev))
+        r["loss"].backward()
+        for k in ("loss", "ade", "fde", "speed", "smooth"):
+            close(r[k], g[f"{tag}/{k}"], rtol=1e-5, atol=1e-6, what=f"{tag}/{k}")
+        close(wp.grad, g[f"{tag}/d_wp"], rtol=1e-4, atol=1e-7)
+        close(spd.grad, g[f"{tag}/d_spd"], rtol=1e-4, atol=1e-7)
+
+
+def test_carla_detection_loss_vs_oracle():
+    """CARLA fine-tuning loss glue (matched-only class loss, 0.0 without matches, bbox weight 1.0) on the device vs the
+    oracle restatement, values and gradients w.r.t. the head outputs; ragged target counts incl. an image without boxes."""
+    from oracle import losses as olosses
+    from oracle.matcher import HungarianMatcher as OM
+    from self_driving_model_amd.training.hungarian_matcher import HungarianMatcher
+    from self_driving_model_amd.training.train_bdd100k_ddp import detection_set_loss
+    dev = _dev()
+    B, C, h, w = 3, 10, 5, 8
+    boxes = -torch.ones(B, 6, 4)
+    labels = -torch.ones(B, 6, dtype=torch.int64)
+    gb = torch.rand(2, 6, 2, generator=torch.Generator().manual_seed(5)) * 50
+    for b, n in ((0, 4), (2, 6)):  # image 1 has no boxes
+        xy = gb[0 if b == 0 else 1, :n]
+        boxes[b, :n] = torch.cat([xy, xy + 5 + gb[0, :n]], dim=1)
+        labels[b, :n] = torch.arange(n) % C
+    for empty in (False, True):
+        gbx, glb = (-torch.ones_like(boxes), -torch.ones_like(labels)) if empty else (boxes, labels)
+        lr_in = seeded_tensor((B, C, h, w), 21).requires_grad_()
+        br_in = (seeded_tensor((B, 4, h, w), 22) * 20 + 30).requires_grad_()
+        tot_r, cls_r, box_r, _ = olosses.carla_detection_loss({"class_logits": lr_in, "bbox_deltas": br_in}, gbx, glb, C, OM(), 1.0)
+        lh = lr_in.detach().clone().to(dev).requires_grad_()
+        bh = br_in.detach().clone().to(dev).requires_grad_()
+        tot, cls, box, _ = detection_set_loss({"class_logits": lh, "bbox_deltas": bh}, gbx.to(dev), glb.to(dev), C, HungarianMatcher(), 1.0,
+                                              zero_when_unmatched=True)
+        close(tot, tot_r, rtol=1e-4, atol=1e-6); close(cls, cls_r, rtol=1e-4, atol=1e-6); close(box, box_r, rtol=1e-4, atol=1e-6)
+        if empty:
+            assert float(tot.detach()) == 0.0
+        else:
+            tot_r.backward(); tot.backward()
+            close(lh.grad, lr_in.grad, rtol=1e-3, atol=1e-6)
+            close(bh.grad, br_in.grad, rtol=1e-3, atol=1e-6)
+
+
+def test_policy_train_step_graph_matches_eager_and_learns():
+    """PolicyTrainStep (train_carla_policy.py glue): the hipGraph-replayed step follows the eager trajectory and the loss goes down."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.policy.trajectory_head import TrajectoryPolicy
+    from self_driving_model_amd.training.train_carla_policy import PolicyTrainStep
+    dev = _dev()
+    batch = {"image": seeded_tensor((4, 3, 64, 96), 1).to(dev), "waypoints": seeded_tensor((4, 8, 2), 2).to(dev), "speed": seeded_tensor((4, 8), 3).to(dev),
+             "context": seeded_tensor((4, 16), 4).to(dev)}
+    traj = {}
+    with runtime.precision(torch.float32):
+        for mode in (False, True):
+            m = seed_module_(TrajectoryPolicy(horizon=8, context_dim=16), 9).to(dev).train()
+            for d in m.modules():
+                if isinstance(d, torch.nn.Dropout):
+                    d.p = 0.0
+            step = PolicyTrainStep(m, lr=1e-3, use_graph=mode)
+            traj[mode] = [float(step(batch)["loss"]) for _ in range(6)]
+            assert (step._graph is not None) == mode
+    assert traj[False][-1] < traj[False][0]
+    np.testing.assert_allclose(traj[True], traj[False], rtol=2e-3, atol=1e-4)

@@ -309,3 +309,33 @@ def test_four_expert_reference_config_oracle():
         o = m({"image": seeded_tensor((1, 3, 64, 96), 5), "speed": seeded_tensor((1, 10), 6)})
     assert o["expert_weights"].shape == (1, 4) and abs(float(o["expert_weights"].sum()) - 1) < 1e-6
     assert o["expert_outputs"][3]["class_logits"].shape == (1, 196, 10) and o["expert_outputs"][3]["bbox_preds"].shape == (1, 196, 4)
+
+
+# ---- CARLA trainers' loss glue ----
+def test_policy_losses_match_reference(golden_dir):
+    """oracle.policy_losses and the product's torch-op `compute_losses` vs the reference function compiled from source."""
+    from self_driving_model_amd.training.train_carla_policy import compute_losses
+    g = _load(golden_dir, "policy_losses")
+    for tag, (B, T) in {"b6t8": (6, 8), "b32t10": (32, 10), "b3t3": (3, 3)}.items():
+        for fn in (olosses.policy_losses, compute_losses):
+            wp = seeded_tensor((B, T, 2), 900 + B).requires_grad_()
+            spd = seeded_tensor((B, T), 901 + B).requires_grad_()
+            r = fn({"waypoints": wp, "speed": spd}, seeded_tensor((B, T, 2), 902 + B), seeded_tensor((B, T), 903 + B))
+            r["loss"].backward()
+            for k in ("loss", "ade", "fde", "speed", "smooth"):
+                np.testing.assert_allclose(r[k].detach().double().numpy(), g[f"{tag}/{k}"], rtol=1e-6, atol=1e-7, err_msg=f"{tag}/{k}")
+            np.testing.assert_allclose(wp.grad.numpy(), g[f"{tag}/d_wp"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(spd.grad.numpy(), g[f"{tag}/d_spd"], rtol=1e-5, atol=1e-8)
+
+
+def test_carla_mask_sanitising_and_empty_detection_batch():
+    from self_driving_model_amd.training.train_carla_bdd_experts_ddp import sanitize_mask
+    m = torch.tensor([[[0, 2, 3, -1], [255, 1, 7, 2]]])
+    exp = olosses.carla_sanitize_mask(m, 3)
+    assert torch.equal(sanitize_mask(m, 3), exp) and exp.tolist() == [[[0, 2, 255, 255], [255, 1, 255, 2]]]
+    assert torch.equal(sanitize_mask(m[..., None].expand(-1, -1, -1, 3), 3), exp)  # trailing channel axis dropped
+    # a batch without any ground-truth box: both loss terms are exactly 0.0 (the BDD100K trainer's CE would be NaN)
+    out = {"class_logits": seeded_tensor((2, 10, 3, 4), 1), "bbox_deltas": seeded_tensor((2, 4, 3, 4), 2)}
+    total, cls, box, _ = olosses.carla_detection_loss(out, -torch.ones(2, 5, 4), -torch.ones(2, 5, dtype=torch.int64), 10,
+                                                      omatcher.HungarianMatcher())
+    assert float(total) == 0.0 and float(cls) == 0.0 and float(box) == 0.0
