@@ -146,6 +146,12 @@ int am_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H,
  * [B,H/2,W/2,16] `dtype`, channel (py*2+px)*C + c = img[b,c,2Y+py,2X+px].  A stride-2 KxK conv on the image becomes a
  * stride-1 conv with 16 input channels on this tensor (7x7 -> 4x4 taps, 5x5 -> 3x3 taps). */
 int am_image_s2d(int dtype, const float* src, void* dst, int B, int C, int H, int W, am_stream_t stream);
+/* The same boundary for raw frames: uint8 NCHW [B,C,H,W] -> (u/255 - mean[c]) / std[c] computed in fp32 exactly as the
+ * reference's loader does (dataloaders/bdd_detection_loader.py:54 `read_image(...).float() / 255.0`; optional torchvision
+ * Normalize, train_bdd100k_ddp.py:471-473) -> space-to-depth NHWC `dtype` [B,ceil(H/2),ceil(W/2),16] (odd sizes: the missing
+ * row / column is zero).  mean/std are HOST arrays of C floats, both NULL for /255 only. */
+int am_image_u8_s2d(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, const float* mean,
+                    const float* stdv, am_stream_t stream);
 int am_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int ld, float mul,
                     am_stream_t stream);
 int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int B, int IH, int IW, int C,

@@ -62,6 +62,42 @@ __global__ __launch_bounds__(256) void image_s2d_k(const float* __restrict__ src
   }
 }
 
+// Same boundary for raw camera frames: uint8 NCHW -> (u/255 - mean[c]) / std[c] in fp32 (the reference's loader arithmetic:
+// read_image(...).float() / 255.0, then torchvision Normalize = sub mean, div std; bdd_detection_loader.py:54,
+// train_bdd100k_ddp.py:471-473) -> space-to-depth NHWC.  One pass, a quarter of the bytes of the fp32 image on the way in.
+template <typename T>
+__global__ __launch_bounds__(256) void image_u8_s2d_k(const uint8_t* __restrict__ src, T* __restrict__ dst, int C, int H, int W,
+                                                      long long total, float m0, float m1, float m2, float m3, float s0, float s1,
+                                                      float s2, float s3, int normalize) {
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;  // odd sizes: the missing row / column is zero AFTER the preprocessing
+  const float mean[4] = {m0, m1, m2, m3}, stdv[4] = {s0, s1, s2, s3};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W2);
+    long long t = i / W2;
+    const int Y = (int)(t % H2);
+    const long long b = t / H2;
+    T out[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = am_from_f32<T>(0.f);
+    for (int c = 0; c < C; ++c) {
+      const uint8_t* pl = src + (b * C + c) * (long long)H * W;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = 2 * Y + (k >> 1), x = 2 * X + (k & 1);
+        if (y < H && x < W) {
+          float v = (float)pl[(long long)y * W + x] / 255.0f;
+          if (normalize) v = (v - mean[c]) / stdv[c];
+          out[k * C + c] = am_from_f32<T>(v);
+        }
+      }
+    }
+    uint4* d = reinterpret_cast<uint4*>(dst + i * 16);
+    const uint4* o = reinterpret_cast<const uint4*>(out);
+#pragma unroll
+    for (int e = 0; e < (int)(16 * sizeof(T) / 16); ++e) d[e] = o[e];
+  }
+}
+
 // ---- NHWC T -> NCHW fp32 (first C channels) -------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src, float* __restrict__ dst, int C, long long HW,
@@ -452,6 +488,23 @@ extern "C" int am_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, in
   if (total == 0) return AM_OK;
   if (dtype == AM_F16) hipLaunchKernelGGL(nchw_to_nhwc_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (half_t*)dst, C, HW, ld, total, mul);
   else hipLaunchKernelGGL(nchw_to_nhwc_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (float*)dst, C, HW, ld, total, mul);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_image_u8_s2d(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, const float* mean,
+                               const float* stdv, am_stream_t stream) {
+  if (!DT_OK(dtype) || !src || !dst || C < 1 || C > 4 || H < 1 || W < 1 || B < 0 || ((mean == nullptr) != (stdv == nullptr)))
+    return AM_ERR_ARG;
+  const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  if (total == 0) return AM_OK;
+  float m[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {1.f, 1.f, 1.f, 1.f};
+  const int normalize = mean != nullptr;
+  for (int c = 0; c < C && normalize; ++c) { m[c] = mean[c]; sd[c] = stdv[c]; }
+  if (dtype == AM_F16)
+    hipLaunchKernelGGL(image_u8_s2d_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (half_t*)dst, C, H, W, total, m[0], m[1], m[2], m[3], sd[0], sd[1], sd[2], sd[3], normalize);
+  else
+    hipLaunchKernelGGL(image_u8_s2d_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), src, (float*)dst, C, H, W, total, m[0], m[1], m[2], m[3], sd[0], sd[1], sd[2], sd[3], normalize);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

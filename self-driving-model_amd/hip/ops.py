@@ -34,23 +34,33 @@ def _grad_ready(p) -> bool:
 # boundary layout
 # --------------------------------------------------------------------------------------------
 def image_to_s2d(img: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[B,3,H,W] fp32 NCHW (the reference's batch['image']) -> space-to-depth(2) NHWC [B,ceil(H/2),ceil(W/2),16] `dtype`
+    """[B,3,H,W] fp32 NCHW (the reference's batch['image']) -- or uint8 raw frames, which are scaled by 1/255 and, when
+    runtime.set_input_normalization(mean, std) is set, normalised exactly like the reference's loader (SURVEY.md section 8(f)
+    row 4) -- -> space-to-depth(2) NHWC [B,ceil(H/2),ceil(W/2),16] `dtype`
     (channel (py*2+px)*3 + c = img[b,c,2Y+py,2X+px]); the 3-channel stride-2 first layers run on it as stride-1 convs with
     16 input channels.  The original size rides along as `.orig_hw`.  No gradient: the image is never a leaf that requires
     grad on this path.  Odd sizes are zero-padded by one row/column, which the convs' own zero padding makes exact."""
     require_hip(img, "image")
     img = img.detach()
-    if img.dtype != torch.float32:
+    raw_u8 = img.dtype == torch.uint8
+    if not raw_u8 and img.dtype != torch.float32:
         img = img.float()
     B, C, H, W = img.shape
     if C > 4:
         raise ValueError(f"image has {C} channels; the first-layer path handles at most 4")
-    if (H & 1) or (W & 1):
+    if ((H & 1) or (W & 1)) and not raw_u8:
         img = torch.nn.functional.pad(img, (0, W & 1, 0, H & 1))
     img = img.contiguous()
-    H2, W2 = img.shape[2] // 2, img.shape[3] // 2
+    H2, W2 = (img.shape[2] + 1) // 2, (img.shape[3] + 1) // 2
     out = torch.empty((B, H2, W2, 16), dtype=dtype, device=img.device)
-    _L().am_image_s2d(dt_code(dtype), ptr(img), ptr(out), B, C, img.shape[2], img.shape[3], stream())
+    if raw_u8:
+        # raw camera frames: /255 and the optional ImageNet normalisation happen inside the layout kernel
+        norm = _runtime().input_normalization()
+        mean = (ctypes.c_float * C)(*norm[0][:C]) if norm is not None else None
+        std = (ctypes.c_float * C)(*norm[1][:C]) if norm is not None else None
+        _L().am_image_u8_s2d(dt_code(dtype), ptr(img), ptr(out), B, C, img.shape[2], img.shape[3], mean, std, stream())
+    else:
+        _L().am_image_s2d(dt_code(dtype), ptr(img), ptr(out), B, C, img.shape[2], img.shape[3], stream())
     out.orig_hw = (H, W)
     return out
 

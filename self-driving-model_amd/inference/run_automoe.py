@@ -12,8 +12,6 @@ import torch.nn as nn
 from .. import runtime
 from ..models.automoe import create_automoe_model
 
-_MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
-_STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
 
 def load_model(model_config_path: str, checkpoint_path: str, device: torch.device) -> nn.Module:
@@ -36,10 +34,16 @@ def model_infer(model: nn.Module, image_rgb: np.ndarray, last_speed_kmh: float, 
     if img_tf is not None:
         tensor = img_tf(image_rgb).unsqueeze(0).to(device)
     else:
-        t = torch.from_numpy(np.ascontiguousarray(image_rgb)).to(device).permute(2, 0, 1).unsqueeze(0).float() / 255.0
-        tensor = (t - _MEAN.to(device)) / _STD.to(device)
+        # raw frame: /255 and the ImageNet normalisation run inside the boundary layout kernel (hip.ops.image_to_s2d)
+        tensor = torch.from_numpy(np.ascontiguousarray(image_rgb)).to(device).permute(2, 0, 1).unsqueeze(0).contiguous()
     batch: Dict[str, Any] = {"image": tensor, "speed": torch.tensor([[last_speed_kmh]], dtype=torch.float32, device=device),
                              "steering": torch.zeros(1, 1, device=device), "throttle": torch.zeros(1, 1, device=device),
                              "brake": torch.zeros(1, 1, device=device)}
-    with runtime.precision(torch.float16):
-        return model(batch)
+    prev = runtime.input_normalization()
+    try:
+        if tensor.dtype == torch.uint8:
+            runtime.set_input_normalization(runtime.IMAGENET_MEAN, runtime.IMAGENET_STD)
+        with runtime.precision(torch.float16):
+            return model(batch)
+    finally:
+        runtime.set_input_normalization(*(prev if prev is not None else (None, None)))

@@ -28,6 +28,23 @@ def set_compute_dtype(dtype: torch.dtype, loss_scale: float | None = None):
         _STATE["loss_scale"] = float(loss_scale)
 
 
+_INPUT_NORM = None
+
+
+def set_input_normalization(mean=None, std=None) -> None:
+    """Per-channel (mean, std) applied to uint8 input frames after the /255 scaling, inside the boundary layout kernel
+    (train_bdd100k_ddp.py:471-473 `--imagenet_norm`: mean [0.485, 0.456, 0.406], std [0.229, 0.224, 0.225]).  None: /255 only.
+    fp32 images are taken as already preprocessed, as the reference's models do."""
+    global _INPUT_NORM
+    _INPUT_NORM = None if mean is None else (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+
+
+def input_normalization():
+    return _INPUT_NORM
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
 _DIRECT_GRADS = False
 
 

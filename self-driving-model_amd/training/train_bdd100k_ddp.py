@@ -179,6 +179,8 @@ def main(argv=None):
     args = p.parse_args(argv)
     from .. import runtime
     runtime.set_compute_dtype(torch.float16 if args.precision == "fp16" else torch.float32)
+    if args.imagenet_norm:  # applied to uint8 frames inside the boundary layout kernel (the reference: T.Normalize in the loader)
+        runtime.set_input_normalization(runtime.IMAGENET_MEAN, runtime.IMAGENET_STD)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         dist.init_process_group(backend="nccl", init_method="env://")  # RCCL
         local = int(os.environ.get("LOCAL_RANK", 0))

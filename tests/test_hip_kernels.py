@@ -474,3 +474,29 @@ def test_conv_big_tile_variant_vs_torch(case):
     st_ = stats.view(16, 2, cout).sum(0).cpu()
     np.testing.assert_allclose(st_[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=1.0)
     np.testing.assert_allclose(st_[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_uint8_frames_boundary_matches_reference_preprocessing(norm):
+    """uint8 frames -> /255 (-> ImageNet normalise) -> space-to-depth NHWC in one kernel,
+    against the reference loader's arithmetic (`read_image(...).float() / 255.0`, torchvision Normalize = sub mean, div std)
+    done in torch on the CPU and fed through the fp32 boundary: bit-exact in fp32, identical after rounding in f16; an odd
+    frame size takes the fallback path and must agree too."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    try:
+        runtime.set_input_normalization(runtime.IMAGENET_MEAN, runtime.IMAGENET_STD) if norm else runtime.set_input_normalization(None)
+        for shape in ((2, 3, 64, 96), (1, 3, 33, 47)):
+            u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+            ref = u8.float() / 255.0
+            if norm:
+                ref = (ref - torch.tensor(runtime.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(runtime.IMAGENET_STD).view(1, 3, 1, 1)
+            for dt in (torch.float32, torch.float16):
+                a = hops.image_to_s2d(u8.to(dev), dt)
+                b = hops.image_to_s2d(ref.to(dev), dt)
+                assert a.orig_hw == b.orig_hw == tuple(shape[2:])
+                assert torch.equal(a, b), (shape, dt)
+    finally:
+        runtime.set_input_normalization(None)

@@ -758,3 +758,46 @@ def test_policy_train_step_graph_matches_eager_and_learns():
             assert (step._graph is not None) == mode
     assert traj[False][-1] < traj[False][0]
     np.testing.assert_allclose(traj[True], traj[False], rtol=2e-3, atol=1e-4)
+
+
+def test_reference_format_checkpoints_round_trip(tmp_path):
+    """checkpoints in the reference's formats -- per-expert `best.pth` dicts
+    (train_bdd100k_ddp.py:401-420, loaded by AutoMoE.load_expert_checkpoints, automoe.py:237-267) and a gating-stage
+    checkpoint saved under DDP with `module.` prefixes (train_gating_network.py:170, loaded by inference load_model) --
+    written from the oracle model, loaded with weights_only, same eval outputs; uint8 frames through model_infer."""
+    import json
+    from oracle import torch_ref as oref
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.inference.run_automoe import load_model, model_infer
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    ref = seed_module_(oref.create_automoe_model(FOUR_EXPERT_CFG, "cpu"), 123).eval()
+    cfg_path = tmp_path / "model_config.json"
+    cfg_path.write_text(json.dumps(FOUR_EXPERT_CFG))
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: v for k, v in ref.state_dict().items()}, "best_val_loss": 1.0},
+               tmp_path / "gating_best.pth")
+    hip = load_model(str(cfg_path), str(tmp_path / "gating_best.pth"), _dev())
+    batch = _batch(2, 64, 96, 7)
+    with torch.no_grad():
+        o_r = ref(batch)
+        with runtime.precision(torch.float32):
+            o = hip({k: v.to(_dev()) for k, v in batch.items()})
+    for k in ("waypoints", "speed", "expert_weights", "gate_logits"):
+        close(o[k], o_r[k], what=k)
+    # per-expert checkpoints into a fresh model
+    fresh = create_automoe_model(FOUR_EXPERT_CFG, _dev())
+    paths = []
+    for i, e in enumerate(ref.experts):
+        p = tmp_path / f"expert{i}_best.pth"
+        torch.save({"epoch": 1, "model_state_dict": e.state_dict(), "optimizer_state_dict": None, "best_val_loss": 0.5, "config": {}}, p)
+        paths.append(str(p))
+    fresh.load_expert_checkpoints(paths)
+    for (n, a), (_, b) in zip(fresh.experts.state_dict().items(), ref.experts.state_dict().items()):
+        assert torch.equal(a.cpu(), b), n
+    # raw uint8 frame through the inference entry point == the reference preprocessing done by hand (f16 tolerance)
+    frame = np.random.default_rng(0).integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    out = model_infer(hip, frame, 12.0, _dev())
+    t = torch.from_numpy(frame).permute(2, 0, 1)[None].float() / 255.0
+    t = (t - torch.tensor(runtime.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(runtime.IMAGENET_STD).view(1, 3, 1, 1)
+    with torch.no_grad():
+        o_r = ref({"image": t, "speed": torch.tensor([[12.0]]), "steering": torch.zeros(1, 1), "throttle": torch.zeros(1, 1), "brake": torch.zeros(1, 1)})
+    assert rel_err(out["waypoints"], o_r["waypoints"]) < 5e-2 and runtime.input_normalization() is None
