@@ -140,3 +140,24 @@ def carla_sanitize_mask(mask: torch.Tensor, num_classes: int) -> torch.Tensor:
         mask = mask.clone()
         mask[invalid] = 255
     return mask
+
+
+def nuscenes_set_loss(model_out: Dict[str, torch.Tensor], gt_boxes: torch.Tensor, gt_labels: torch.Tensor, matcher: HungarianMatcher,
+                      bbox_loss_weight: float = 5.0):
+    """training/train_nuscenes_expert_ddp.py:73-112: CE(ignore_index=-1) over all queries (unmatched = -1); SmoothL1('none')
+    of ALL query boxes vs a target that is zero for unmatched queries, mean over every element."""
+    logits, boxes = model_out["class_logits"], model_out["bbox_preds"]
+    B, Q, C = logits.shape
+    targets = []
+    for i in range(B):
+        keep = gt_labels[i] != -1
+        targets.append({"boxes": gt_boxes[i][keep], "labels": gt_labels[i][keep]})
+    indices = matcher({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    tgt_classes = torch.full((B, Q), -1, dtype=torch.int64)
+    tgt_boxes = torch.zeros_like(boxes)
+    for i, (pi, ti) in enumerate(indices):
+        tgt_classes[i, pi] = targets[i]["labels"][ti]
+        tgt_boxes[i, pi] = targets[i]["boxes"][ti]
+    loss_cls = F.cross_entropy(logits.view(-1, C), tgt_classes.view(-1), ignore_index=-1)
+    loss_bbox = F.smooth_l1_loss(boxes, tgt_boxes, reduction="none").mean()
+    return loss_cls + bbox_loss_weight * loss_bbox, loss_cls, loss_bbox, indices

@@ -801,3 +801,35 @@ def test_reference_format_checkpoints_round_trip(tmp_path):
     with torch.no_grad():
         o_r = ref({"image": t, "speed": torch.tensor([[12.0]]), "steering": torch.zeros(1, 1), "throttle": torch.zeros(1, 1), "brake": torch.zeros(1, 1)})
     assert rel_err(out["waypoints"], o_r["waypoints"]) < 5e-2 and runtime.input_normalization() is None
+
+
+@pytest.mark.parametrize("D", [7, 4])
+def test_nuscenes_set_loss_vs_oracle(D):
+    """train_nuscenes_expert_ddp.py loss glue on the device (matcher with the D = 7 BEV cost, scatter, CE(ignore -1) over all
+    queries, SmoothL1 over ALL query boxes against zero-filled targets) vs the oracle restatement: values and gradients."""
+    from oracle import losses as olosses
+    from oracle.matcher import HungarianMatcher as OM
+    from self_driving_model_amd.training.hungarian_matcher import HungarianMatcher
+    from self_driving_model_amd.training.train_nuscenes_expert_ddp import nuscenes_set_loss
+    dev = _dev()
+    B, Q, C, M = 3, 24, 10, 6
+    gb = seeded_tensor((B, M, D), 31) * 5
+    if D == 7:
+        gb[..., 3:5] = gb[..., 3:5].abs() + 0.5
+    else:
+        gb[..., 2:4] = gb[..., 2:4].abs() + 0.5
+    gl = (seeded_tensor((B, M), 32).abs() * 4).long().clamp(0, C - 1)
+    for b, n in enumerate((4, 0, 6)):
+        gb[b, n:] = -1.0
+        gl[b, n:] = -1
+    lg_r = seeded_tensor((B, Q, C), 33).requires_grad_()
+    bx_r = (seeded_tensor((B, Q, D), 34) * 3).requires_grad_()
+    tot_r, cls_r, box_r, _ = olosses.nuscenes_set_loss({"class_logits": lg_r, "bbox_preds": bx_r}, gb, gl, OM(), 5.0)
+    tot_r.backward()
+    lg = lg_r.detach().clone().to(dev).requires_grad_()
+    bx = bx_r.detach().clone().to(dev).requires_grad_()
+    tot, cls, box, _ = nuscenes_set_loss({"class_logits": lg, "bbox_preds": bx}, gb.to(dev), gl.to(dev), HungarianMatcher(), 5.0)
+    tot.backward()
+    close(tot, tot_r, rtol=1e-4, atol=1e-6); close(cls, cls_r, rtol=1e-4, atol=1e-6); close(box, box_r, rtol=1e-4, atol=1e-6)
+    close(lg.grad, lg_r.grad, rtol=1e-3, atol=1e-6)
+    close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
