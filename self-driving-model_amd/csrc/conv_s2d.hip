@@ -101,8 +101,12 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
   __syncthreads();
 
   float st_s[NT], st_q[NT], sc[NT], sh[NT], bv[NT];
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  f32x8 sv[NT], qv[NT];  // MODE 1: per-register-pair partial sums (packed adds / FMAs per tile), folded once at the end
 #pragma unroll
   for (int tn = 0; tn < NT; ++tn) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sv[tn][r] = 0.f; qv[tn][r] = 0.f; }
     st_s[tn] = st_q[tn] = 0.f;
     const int col = tn * 32 + (lane & 31);
     sc[tn] = (MODE == 2 && col < p.N) ? p.scale[col] : 1.f;
@@ -116,30 +120,47 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
     if (next < p.ntiles) issue_patch(next, buf ^ 1);
     const char* pt = patch0 + buf * PATCH_SLOT;
 
+    // KSTEPS k16 steps (one per tap), software-pipelined by hand: the fragment reads of step s are issued while the MFMAs
+    // of step s-2 run; the counted wait is the builtin so that hipcc's waitcnt pass sees it (see conv_patch.hip).
     f32x16 acc[2][NT];
+    half8_t fa[3][2], fb[3][NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-#pragma unroll
-    for (int i = 0; i < TAPS; ++i) {
-#pragma unroll
-      for (int j = 0; j < TAPS; ++j) {
+    for (int s = 0; s < KSTEPS + 2; ++s) {
+      if (s >= 2) {
+        if (s == KSTEPS + 1) __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+        else if (NT == 2) __builtin_amdgcn_s_waitcnt(0xC47F);            // lgkmcnt(4): the reads of step s-1 stay in flight
+        else __builtin_amdgcn_s_waitcnt(0xC37F);                         // lgkmcnt(3)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < KSTEPS) {
+        const int i = s / TAPS, j = s - i * TAPS;
         const int pid0 = (2 * wid + i) * PW + rx + j;
         const int pid1 = pid0 + PW;
-        const half8_t fa0 = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((kg ^ ((pid0 >> 3) & 1)) << 4));
-        const half8_t fa1 = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((kg ^ ((pid1 >> 3) & 1)) << 4));
-        const char* bb = Wl + (lane & 31) * WPITCH + (i * TAPS + j) * 32 + kg * 16;
+        fa[s % 3][0] = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((kg ^ ((pid0 >> 3) & 1)) << 4));
+        fa[s % 3][1] = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((kg ^ ((pid1 >> 3) & 1)) << 4));
+        const char* bb = Wl + (lane & 31) * WPITCH + s * 32 + kg * 16;
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn) {
-          const half8_t fb = *reinterpret_cast<const half8_t*>(bb + tn * 32 * WPITCH);
-          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb, acc[0][tn], 0, 0, 0);
-          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb, acc[1][tn], 0, 0, 0);
+        for (int tn = 0; tn < NT; ++tn) fb[s % 3][tn] = *reinterpret_cast<const half8_t*>(bb + tn * 32 * WPITCH);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s >= 2) {
+        const int c = (s - 2) % 3;
+        if (s == 2) {  // first step starts from the constant zero: no per-tile accumulator clears
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) {
+            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[c][0], fb[c][tn], z, 0, 0, 0);
+            acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[c][1], fb[c][tn], z, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) {
+            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[c][0], fb[c][tn], acc[0][tn], 0, 0, 0);
+            acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[c][1], fb[c][tn], acc[1][tn], 0, 0, 0);
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // next patch has had the MFMA phase to land; drain the DMA before any global store (see conv_patch.hip)
@@ -151,6 +172,34 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
     const int rem = tile - img * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     char* stg = stg0 + wid * STG_WAVE;
+    if (MODE == 1) {
+      // statistics only: whole-vector adds / FMAs into per-register partial sums; pixels outside the image (edge tiles
+      // only) are zeroed first so they add nothing
+      if (ty * TH + TH > p.OH || tx * TW + TW > p.OW) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const bool rowok = ty * TH + 2 * wid + tm < p.OH;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = rowok && tx * TW + (r & 3) + 8 * (r >> 2) + 4 * kg < p.OW;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) acc[tm][tn][r] = ok ? acc[tm][tn][r] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const f32x8 lo = __builtin_shufflevector(acc[tm][tn], acc[tm][tn], 0, 1, 2, 3, 4, 5, 6, 7);
+          const f32x8 hi = __builtin_shufflevector(acc[tm][tn], acc[tm][tn], 8, 9, 10, 11, 12, 13, 14, 15);
+          sv[tn] += lo;
+          sv[tn] += hi;
+          qv[tn] = __builtin_elementwise_fma(lo, lo, qv[tn]);
+          qv[tn] = __builtin_elementwise_fma(hi, hi, qv[tn]);
+        }
+      continue;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int oy = ty * TH + 2 * wid + tm;
@@ -195,6 +244,10 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
   if (MODE != 2 && p.stats != nullptr) {
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) {
+      if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { st_s[tn] += sv[tn][r]; st_q[tn] += qv[tn][r]; }
+      }
       st_s[tn] += __shfl_xor(st_s[tn], 32, 64);
       st_q[tn] += __shfl_xor(st_q[tn], 32, 64);
     }
