@@ -87,6 +87,11 @@ int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w,
 int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
                         const float* shift, void* y, double* stats, am_stream_t stream);
 
+/* Diagnostic (bench.py roofline leg): which kernel the last am_conv_gemm / am_conv_first_fused call of this process launched.
+ * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 conv3x3_c64n64_wreg_k,
+ * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k. */
+int am_conv_last_variant(void);
+
 /* Weight gradient of the same gather-GEMM (torch conv2d backward w.r.t. weight):
  *   dw[n, t*krun + r] += scale * sum_m dy[m, n] * gather(m, t, r),  fp32, atomically accumulated,
  * dw row-major [>=N rows][ntaps*krun] (caller zeroes it, e.g. zero_grad).  `dy` is read at the

@@ -53,3 +53,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 static inline int am_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Diagnostic only (bench.py's roofline leg attributes launch times to kernels): id of the conv kernel the last am_conv_gemm /
+// am_conv_first_fused call on this process launched.  Not synchronised across host threads.
+enum am_conv_variant_id {
+  AM_CV_NONE = 0, AM_CV_RING_256x256, AM_CV_RING_256x128, AM_CV_DUO_C64, AM_CV_WREG_C64, AM_CV_PATCH_C64, AM_CV_LDSDMA_V2,
+  AM_CV_LDSDMA_RING_V1, AM_CV_REGSTAGED, AM_CV_S2D, AM_CV_S2D_POOL
+};
+extern int g_am_conv_variant;

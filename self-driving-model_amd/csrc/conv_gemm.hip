@@ -330,6 +330,7 @@ int launch_conv_m(const ConvKParams& p, hipStream_t s) {
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
+  g_am_conv_variant = AM_CV_REGSTAGED;
   hipLaunchKernelGGL((conv_gemm_k<T, BM, BN, WM, WN, MULTI>), dim3(q.mtiles * q.ntiles), dim3(WM * WN * 64), lds, s, q);
   AM_CHECK_LAUNCH();
   return AM_OK;
@@ -568,6 +569,10 @@ static bool use_v1_only() {
   if (v < 0) { const char* e = getenv("AM_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
 }
+
+int g_am_conv_variant = AM_CV_NONE;
+
+extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
 
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;

@@ -508,6 +508,7 @@ int launch3(const Conv2Params& p0, hipStream_t s) {
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
+  g_am_conv_variant = AM_CV_LDSDMA_RING_V1;
   hipLaunchKernelGGL((conv_gemm3_k<BM, BN, WM, WN, BKB>), dim3(p.mtiles * p.ntiles), dim3(WM * WN * 64), lds, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
@@ -530,6 +531,7 @@ int launch2(const Conv2Params& p0, hipStream_t s) {
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
+  g_am_conv_variant = AM_CV_LDSDMA_V2;
   hipLaunchKernelGGL((conv_gemm2_k<BM, BN, WM, WN, BKB>), dim3(p.mtiles * p.ntiles), dim3(256), lds, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;

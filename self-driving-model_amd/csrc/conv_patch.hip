@@ -289,6 +289,7 @@ int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, c
     attr_done = true;
   }
   const int grid = p.ntiles < 256 ? p.ntiles : 256;  // one persistent workgroup per CU
+  g_am_conv_variant = AM_CV_PATCH_C64;
   hipLaunchKernelGGL(conv3x3_c64n64_k, dim3(grid), dim3(256), LDS_BYTES, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;

@@ -301,6 +301,7 @@ int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* 
     attr_done = true;
   }
   const int grid = p.ntiles < 512 ? ((p.ntiles + 7) & ~7) : 512;  // two persistent workgroups per CU, a multiple of the 8 XCDs
+  g_am_conv_variant = AM_CV_DUO_C64;
   hipLaunchKernelGGL(conv3x3_c64n64_duo_k, dim3(grid), dim3(256), LDS_BYTES, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;

@@ -310,6 +310,7 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
+  g_am_conv_variant = BN >= 256 ? AM_CV_RING_256x256 : AM_CV_RING_256x128;
   hipLaunchKernelGGL((conv_ring_k<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(WM * WN * 64), lds, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;

@@ -291,6 +291,7 @@ int launch_s2d(const S2dParams& p, hipStream_t s) {
   }
   const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
   const int grid = p.ntiles < 256 * per_cu ? p.ntiles : 256 * per_cu;
+  g_am_conv_variant = AM_CV_S2D;
   hipLaunchKernelGGL((conv_s2d_k<TAPS, NT, MODE>), dim3(grid), dim3(256), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
@@ -466,6 +467,7 @@ int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
     attr_done = true;
   }
   const int grid = p.ntiles < 256 ? p.ntiles : 256;
+  g_am_conv_variant = AM_CV_S2D_POOL;
   hipLaunchKernelGGL((conv_s2d_pool_k<TAPS>), dim3(grid), dim3(512), LDS, s, p, POH, POW, pty, ptx);
   AM_CHECK_LAUNCH();
   return AM_OK;

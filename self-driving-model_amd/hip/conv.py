@@ -272,13 +272,15 @@ class KernelTimer:
     `flops` is the ALGORITHMIC count of the launch, 2*M*K*N with the real (unpadded) K."""
 
     def __init__(self):
-        self.records = []  # (kind, flops, ev0, ev1)
+        self.records = []  # (kind, flops, ev0, ev1, kernel)
 
-    def summary(self):
+    def summary(self, by: str = "kind"):
+        """Totals per launch kind ("conv_gemm" / "conv_dgrad" / "conv_wgrad") or, with by="kernel", per kernel the library's
+        dispatcher actually launched (am_conv_last_variant)."""
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1 in self.records:
-            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for kind, flops, e0, e1, kernel in self.records:
+            d = out.setdefault(kind if by == "kind" else kernel, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += e0.elapsed_time(e1)
@@ -286,6 +288,8 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+CONV_KERNEL_NAMES = {1: "conv_ring_k<256,256,2,4>", 2: "conv_ring_k<256,128,4,2>", 3: "conv3x3_c64n64_duo_k", 4: "conv3x3_c64n64_wreg_k",
+                     5: "conv3x3_c64n64_k", 6: "conv_gemm2_k", 7: "conv_gemm3_k", 8: "conv_gemm_k", 9: "conv_s2d_k", 10: "conv_s2d_pool_k"}
 
 
 def _timed(kind: str, flops: float, fn):
@@ -296,7 +300,7 @@ def _timed(kind: str, flops: float, fn):
     e0.record()
     fn()
     e1.record()
-    TIMER.records.append((kind, flops, e0, e1))
+    TIMER.records.append((kind, flops, e0, e1, CONV_KERNEL_NAMES.get(_L().am_conv_last_variant(), "?") if kind != "conv_wgrad" else "conv_wgrad_k"))
 
 
 def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None, k_real: Optional[int] = None, kind: str = "conv_gemm"):

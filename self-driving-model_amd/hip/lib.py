@@ -87,7 +87,7 @@ class _Lib:
             fn.restype = ctypes.c_int
             fn.argtypes = [t for _, t in args]
             setattr(self, "_raw_" + name, fn)
-            if name in ("am_version", "am_conv_npad"):
+            if name in ("am_version", "am_conv_npad", "am_conv_last_variant"):
                 setattr(self, name, fn)
             else:
                 setattr(self, name, self._checked(name, fn))
