@@ -8,12 +8,18 @@ layers = [("l1 3x3 64->64", hc.ConvSpec(64, 64, 3, 1, 1), 180, 320), ("l2.0 3x3 
           ("l2 3x3 128->128", hc.ConvSpec(128, 128, 3, 1, 1), 90, 160), ("l3 3x3 256->256", hc.ConvSpec(256, 256, 3, 1, 1), 45, 80),
           ("l4 3x3 512->512", hc.ConvSpec(512, 512, 3, 1, 1), 23, 40), ("pol1 3x3 32->64 s2", hc.ConvSpec(32, 64, 3, 2, 1), 360, 640),
           ("pol2 3x3 64->128 s2", hc.ConvSpec(64, 128, 3, 2, 1), 180, 320), ("pol3 3x3 128->256 s2", hc.ConvSpec(128, 256, 3, 2, 1), 90, 160)]
+layers = [("pol0 5x5 3->32 s2 (s2d)", hc.ConvSpec(3, 32, 5, 2, 2, first=True), 720, 1280),
+          ("stem 7x7 3->64 s2 (s2d)", hc.ConvSpec(3, 64, 7, 2, 3, first=True), 720, 1280)] + layers
 tot = 0
 for name, s, IH, IW in layers:
-    x = torch.randn(B, IH, IW, s.cin, device=dev).to(dt)
     OH, OW = hc.out_size(IH, s), hc.out_size(IW, s)
+    if s.first:
+        x = torch.randn(B, IH // 2, IW // 2, 16, device=dev).to(dt)
+        g = hc.fwd_geom(s, B, IH // 2, IW // 2, 16, s.cout, 2, orig_hw=(IH, IW))
+    else:
+        x = torch.randn(B, IH, IW, s.cin, device=dev).to(dt)
+        g = hc.fwd_geom(s, B, IH, IW, s.cin, s.cout, 2)
     dy = torch.randn(B, OH, OW, s.cout, device=dev).to(dt)
-    g = hc.fwd_geom(s, B, IH, IW, s.cin, s.cout, 2)
     dwp = torch.zeros(s.cout, g.ntaps * g.krun, dtype=torch.float32, device=dev)
     for _ in range(3): hc.conv_wgrad(g, x, dy, 1.0, dwp)
     torch.cuda.synchronize()

@@ -553,6 +553,7 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 }  // namespace
 
+int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                       hipStream_t s);  // conv_gemm2.hip
 int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
@@ -642,6 +643,12 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
   p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16) {
+    static int s2dw = -1;
+    if (s2dw < 0) { const char* e = getenv("AM_WGRAD_S2D"); s2dw = e ? atoi(e) : 1; }
+    if (s2dw && g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip)
+      rc = am_conv_s2d_wgrad_f16(g, x, dy, scale, dw, s);
+      if (rc != AM_ERR_UNSUPPORTED) return rc;
+    }
     if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s);
     return launch_wgrad<half_t, 64, 4>(p, s);
   }

@@ -1,0 +1,202 @@
+// Weight gradient of the 3-channel first layers on the space-to-depth image (policy conv 5x5/s2 = 3x3 taps, ResNet stem
+// 7x7/s2 = 4x4 taps; forward: conv_s2d.hip).
+//
+// The generic conv_wgrad_k tiles the packed K (taps x 64) in 128-column slabs and re-reads dY once per slab: with
+// M = 7.4 M output pixels and only 32-64 output channels that is 5x 472 MB of dY -- the launch is bound by those re-reads
+// (530 us for the policy layer at B = 32, HBM floor ~150 us).  Here a persistent workgroup walks 8x32-pixel output tiles,
+// stages each tile's dY block and its input patch ONCE in LDS and accumulates the whole [N][taps*64] gradient in
+// registers (pixels are the MFMA reduction dimension: both operands are pixel-major, so fragments come from the
+// ds_read_b64_tr_b16 hardware-transpose read, LDS pitches = 64 mod 128 bytes); one flush per workgroup at the end
+// (LDS reduction across the four waves, then fp32 atomics).
+#include "am_common.h"
+
+namespace amw {
+
+constexpr int TH = 8, TW = 32;
+constexpr int PW = TW + 3;       // patch columns (runs of 4 s2d pixels per tap row)
+constexpr int PPITCH = 64;       // LDS bytes per patch pixel: 32 B of channels + 32 B pad (= 64 mod 128)
+
+struct S2dWgradParams {
+  const void* x;   // s2d image [B, IH, IW, 16] halves
+  const void* dy;  // [B, OH, OW, ldo] halves
+  float* dw;       // packed [>= N][taps*64] fp32, accumulated
+  float scale;
+  int B, IH, IW, OH, OW, ldo, y_coff, off0, N;
+  int tiles_y, tiles_x, ntiles;
+};
+
+typedef __attribute__((address_space(3))) s4v* lds_s4v;
+
+__device__ __forceinline__ half8_t tr_frag(const char* lo_addr, int hi_delta) {
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr + hi_delta));
+  const half4_t l4 = __builtin_bit_cast(half4_t, lo), h4 = __builtin_bit_cast(half4_t, hi);
+  return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+// NT = number of 32-channel blocks of dY (1: N <= 32, 2: N <= 64).  Wave w: NT == 1 -> tile rows 2w, 2w+1; NT == 2 ->
+// channel block w & 1, tile rows 4*(w>>1) .. +3.
+template <int TAPS, int NT>
+__global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) {
+  constexpr int PH = TH + TAPS - 1;
+  constexpr int PATCH_PIX = PH * PW;
+  constexpr int PATCH_BYTES = PATCH_PIX * PPITCH;
+  constexpr int DYB = NT * 64;                      // dY bytes per pixel in LDS (32 channels per block)
+  constexpr int PDY = NT == 1 ? 64 : 192;           // pitch = 64 (mod 128)
+  constexpr int PCH = (PATCH_PIX * 2 + 255) / 256;  // patch 16-byte chunks per thread
+  constexpr int DCH = TH * TW * (DYB / 16) / 256;   // dY chunks per thread
+  constexpr int ROWS = NT == 1 ? 2 : 4;             // tile rows per wave
+  constexpr int KTOT = TAPS * 64;
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* patch = smem;
+  char* dYs = smem + ((PATCH_BYTES + 1023) / 1024) * 1024;
+
+  const half_t* __restrict__ x = static_cast<const half_t*>(p.x);
+  const half_t* __restrict__ dy = static_cast<const half_t*>(p.dy);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int nblk = NT == 1 ? 0 : (wid & 1);
+  const int row0 = NT == 1 ? 2 * wid : 4 * (wid >> 1);
+
+  f32x16 acc[TAPS][2];
+#pragma unroll
+  for (int i = 0; i < TAPS; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jp][r] = 0.f;
+
+  uint4 rp[PCH], rd[DCH];
+  auto load_tile = [&](int tile) {
+    const int img = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - img * (p.tiles_y * p.tiles_x);
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int iy0 = ty * TH + p.off0, ix0 = tx * TW + p.off0;
+#pragma unroll
+    for (int k = 0; k < PCH; ++k) {
+      const int c = tid + k * 256;
+      const int pidx = c >> 1;
+      const int prow = pidx / PW, pcol = pidx - prow * PW;
+      const int iy = iy0 + prow, ix = ix0 + pcol;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (pidx < PATCH_PIX && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+        v = *reinterpret_cast<const uint4*>(x + ((long long)(img * p.IH + iy) * p.IW + ix) * 16 + (c & 1) * 8);
+      rp[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int c = tid + k * 256;
+      const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
+      const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff)
+        v = *reinterpret_cast<const uint4*>(dy + ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8);
+      rd[k] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < PCH; ++k) {
+      const int c = tid + k * 256;
+      if ((c >> 1) < PATCH_PIX) *reinterpret_cast<uint4*>(patch + (c >> 1) * PPITCH + (c & 1) * 16) = rp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int c = tid + k * 256;
+      const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
+      *reinterpret_cast<uint4*>(dYs + pix * PDY + cc * 16) = rd[k];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_tile(tile);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) load_tile(next);  // in flight during the MFMA phase
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int row = row0 + rr;
+#pragma unroll
+      for (int xh = 0; xh < 2; ++xh) {
+        // 16 consecutive pixels of one tile row = the k16 of one MFMA; this lane's pixel for the transpose read
+        const int px = xh * 16 + 8 * (gq >> 1) + q;
+        const half8_t a = tr_frag(dYs + (row * TW + px) * PDY + nblk * 64 + ((gq & 1) * 16 + 4 * pp) * 2, 4 * PDY);
+#pragma unroll
+        for (int i = 0; i < TAPS; ++i)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            // 32 gradient columns = the 16 channels of run pixels 2*jp and 2*jp + 1 (the 16-lane group picks the pixel)
+            const half8_t b = tr_frag(patch + ((row + i) * PW + px + 2 * jp + (gq & 1)) * PPITCH + pp * 8, 4 * PPITCH);
+            acc[i][jp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][jp], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ---- flush: waves that share a channel block add up in LDS, then one fp32 atomic per element per workgroup ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [NT][32][KTOT]
+  for (int e = tid; e < NT * 32 * KTOT; e += 256) red[e] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TAPS; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        atomicAdd(red + (nblk * 32 + n) * KTOT + i * 64 + jp * 32 + (lane & 31), acc[i][jp][r]);
+      }
+  __syncthreads();
+  for (int e = tid; e < NT * 32 * KTOT; e += 256) {
+    const int n = e / KTOT;
+    if (n < p.N) atomicAdd(p.dw + (size_t)n * KTOT + (e - n * KTOT), red[e] * p.scale);
+  }
+}
+
+template <int TAPS, int NT>
+int launch(const S2dWgradParams& p, hipStream_t s) {
+  constexpr int PH = TH + TAPS - 1;
+  constexpr int PATCH = ((PH * PW * PPITCH + 1023) / 1024) * 1024;
+  constexpr int DYS = TH * TW * (NT == 1 ? 64 : 192);
+  constexpr int RED = NT * 32 * TAPS * 64 * 4;
+  constexpr int LDS = (PATCH + DYS) > RED ? (PATCH + DYS) : RED;
+  static bool attr_done = false;
+  if (LDS > 64 * 1024 && !attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_wgrad_k<TAPS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int grid = p.ntiles < 512 ? p.ntiles : 512;  // persistent: two workgroups per CU
+  hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT>), dim3(grid), dim3(256), LDS, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+}  // namespace amw
+
+// Called by am_conv_wgrad (conv_gemm.hip) for first-layer (space-to-depth) geometries in f16; returns AM_ERR_UNSUPPORTED
+// when the shape is not covered so the caller uses the generic kernel.
+int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s) {
+  using namespace amw;
+  if (g->pix_shift != 4 || g->krun != 64 || g->ldi != 16 || g->x_coff != 0) return AM_ERR_UNSUPPORTED;
+  if (g->ntaps < 3 || g->ntaps > 4 || g->N > 64) return AM_ERR_UNSUPPORTED;
+  if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
+  if (g->MH != g->OH || g->MW != g->OW || (g->ldo * 2) % 16 != 0 || (g->y_coff * 2) % 16 != 0) return AM_ERR_UNSUPPORTED;
+  for (int t = 0; t < g->ntaps; ++t)
+    if (g->dy[t] != g->dy[0] + t || g->dx[t] != g->dy[0]) return AM_ERR_UNSUPPORTED;
+  if ((long long)g->B * g->OH * g->OW < 2048) return AM_ERR_UNSUPPORTED;  // tiny problems: generic kernel
+  S2dWgradParams p;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+  p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.OH = g->OH; p.OW = g->OW; p.ldo = g->ldo; p.y_coff = g->y_coff;
+  p.off0 = g->dy[0]; p.N = g->N;
+  p.tiles_y = am_cdiv(g->OH, TH);
+  p.tiles_x = am_cdiv(g->OW, TW);
+  p.ntiles = p.B * p.tiles_y * p.tiles_x;
+  if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1>(p, s) : launch<4, 1>(p, s);
+  return g->ntaps == 3 ? launch<3, 2>(p, s) : launch<4, 2>(p, s);
+}
