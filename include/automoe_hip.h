@@ -98,6 +98,14 @@ int am_conv_last_variant(void);
  * geometry's OUTPUT pixels (pixel stride ldo, channel y_coff).  `scale` undoes loss scaling. */
 int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale,
                   float* dw, am_stream_t stream);
+/* am_bn_bwd_apply + am_conv_wgrad in one launch for a layer whose input needs no gradient (the 3-channel first layers:
+ * trajectory_head.py:10-12 conv -> BN -> ReLU on the image): `dy` is the gradient w.r.t. the BN(+ReLU) output, `raw` the conv
+ * output, `yout` the BN+ReLU output (ReLU mask; NULL without ReLU), mean/rstd the saved batch statistics, coef = [3][N] from
+ * am_bn_bwd_finalize; the gradient w.r.t. the conv output is formed on the fly with am_bn_bwd_apply's arithmetic and never
+ * written.  Returns AM_ERR_UNSUPPORTED unless the geometry is a space-to-depth first layer in f16 (caller: the two-step form). */
+int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,
+                     const float* mean, const float* rstd, const float* coef, int relu, float scale, float* dw,
+                     am_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -553,7 +553,8 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 }  // namespace
 
-int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
+int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
+                          const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                       hipStream_t s);  // conv_gemm2.hip
 int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
@@ -646,13 +647,24 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
     static int s2dw = -1;
     if (s2dw < 0) { const char* e = getenv("AM_WGRAD_S2D"); s2dw = e ? atoi(e) : 1; }
     if (s2dw && g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip)
-      rc = am_conv_s2d_wgrad_f16(g, x, dy, scale, dw, s);
+      rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
     if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s);
     return launch_wgrad<half_t, 64, 4>(p, s);
   }
   return launch_wgrad<float, 64, 4>(p, s);
+}
+
+extern "C" int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,
+                                const float* mean, const float* rstd, const float* coef, int relu, float scale, float* dw,
+                                am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !dy || !raw || !mean || !rstd || !coef || !dw || (relu && !yout) || g->ntaps <= 0) return AM_ERR_ARG;
+  if (dtype != AM_F16 || g->pix_shift != 4) return AM_ERR_UNSUPPORTED;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
+  return am_conv_s2d_wgrad_f16(g, x, dy, yout, raw, mean, rstd, coef, relu, scale, dw, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,

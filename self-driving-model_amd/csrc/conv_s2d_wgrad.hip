@@ -23,6 +23,12 @@ struct S2dWgradParams {
   float scale;
   int B, IH, IW, OH, OW, ldo, y_coff, off0, N;
   int tiles_y, tiles_x, ntiles;
+  // BNF (fused BatchNorm backward): dy is the gradient w.r.t. the BN(+ReLU) OUTPUT; the gradient w.r.t. the conv output is
+  // formed while the tile is loaded, exactly as am_bn_bwd_apply would have written it (bn.hip bn_bwd_apply_k)
+  const void* raw;   // conv output (BN input), same layout as dy
+  const void* yout;  // BN+ReLU output (ReLU mask), NULL without ReLU
+  const float* mean; const float* rstd; const float* coef;  // coef = [3][N] from am_bn_bwd_finalize
+  int relu;
 };
 
 typedef __attribute__((address_space(3))) s4v* lds_s4v;
@@ -36,7 +42,7 @@ __device__ __forceinline__ half8_t tr_frag(const char* lo_addr, int hi_delta) {
 
 // NT = number of 32-channel blocks of dY (1: N <= 32, 2: N <= 64).  Wave w: NT == 1 -> tile rows 2w, 2w+1; NT == 2 ->
 // channel block w & 1, tile rows 4*(w>>1) .. +3.
-template <int TAPS, int NT>
+template <int TAPS, int NT, bool BNF>
 __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) {
   constexpr int PH = TH + TAPS - 1;
   constexpr int PATCH_PIX = PH * PW;
@@ -67,6 +73,20 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jp][r] = 0.f;
 
+  // BNF: this thread always loads the same 8-channel chunk of a pixel (256 threads, 4 or 8 chunks per pixel)
+  float bn_mu[8], bn_rs[8], bn_c0[8], bn_c1[8], bn_c2[8];
+  if constexpr (BNF) {
+    const int c0 = (tid % (DYB / 16)) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(c0 + e, p.N - 1);
+      bn_mu[e] = p.mean[c]; bn_rs[e] = p.rstd[c];
+      bn_c0[e] = p.coef[c]; bn_c1[e] = p.coef[p.N + c]; bn_c2[e] = p.coef[2 * p.N + c];
+    }
+  }
+  const half_t* __restrict__ raw = static_cast<const half_t*>(p.raw);
+  const half_t* __restrict__ yout = static_cast<const half_t*>(p.yout);
+
   uint4 rp[PCH], rd[DCH];
   auto load_tile = [&](int tile) {
     const int img = tile / (p.tiles_y * p.tiles_x);
@@ -90,8 +110,25 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
       const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
       const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff)
-        v = *reinterpret_cast<const uint4*>(dy + ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8);
+      if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff) {
+        const long long off = ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8;
+        v = *reinterpret_cast<const uint4*>(dy + off);
+        if constexpr (BNF) {
+          const uint4 xr = *reinterpret_cast<const uint4*>(raw + off);
+          uint4 yr = make_uint4(0u, 0u, 0u, 0u);
+          if (p.relu) yr = *reinterpret_cast<const uint4*>(yout + off);
+          const half8_t gv = __builtin_bit_cast(half8_t, v), xv = __builtin_bit_cast(half8_t, xr), yv = __builtin_bit_cast(half8_t, yr);
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float dz = (float)gv[e];
+            if (p.relu && !((float)yv[e] > 0.f)) dz = 0.f;
+            const float xhat = ((float)xv[e] - bn_mu[e]) * bn_rs[e];
+            o[e] = cc * 8 + e < p.N ? (half_t)(bn_c0[e] * (dz - bn_c1[e] - xhat * bn_c2[e])) : (half_t)0.f;
+          }
+          v = __builtin_bit_cast(uint4, o);
+        }
+      }
       rd[k] = v;
     }
   };
@@ -158,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
   }
 }
 
-template <int TAPS, int NT>
+template <int TAPS, int NT, bool BNF>
 int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int PH = TH + TAPS - 1;
   constexpr int PATCH = ((PH * PW * PPITCH + 1023) / 1024) * 1024;
@@ -167,21 +204,23 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int LDS = (PATCH + DYS) > RED ? (PATCH + DYS) : RED;
   static bool attr_done = false;
   if (LDS > 64 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_wgrad_k<TAPS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_wgrad_k<TAPS, NT, BNF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   const int grid = p.ntiles < 512 ? p.ntiles : 512;  // persistent: two workgroups per CU
-  hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT>), dim3(grid), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT, BNF>), dim3(grid), dim3(256), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
 
 }  // namespace amw
 
-// Called by am_conv_wgrad (conv_gemm.hip) for first-layer (space-to-depth) geometries in f16; returns AM_ERR_UNSUPPORTED
-// when the shape is not covered so the caller uses the generic kernel.
-int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s) {
+// Called by am_conv_wgrad / am_conv_wgrad_bn (conv_gemm.hip) for first-layer (space-to-depth) geometries in f16; returns
+// AM_ERR_UNSUPPORTED when the shape is not covered so the caller uses the generic kernel(s).  raw != NULL selects the fused
+// BatchNorm-backward form.
+int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
+                          const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s) {
   using namespace amw;
   if (g->pix_shift != 4 || g->krun != 64 || g->ldi != 16 || g->x_coff != 0) return AM_ERR_UNSUPPORTED;
   if (g->ntaps < 3 || g->ntaps > 4 || g->N > 64) return AM_ERR_UNSUPPORTED;
@@ -197,6 +236,12 @@ int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, 
   p.tiles_y = am_cdiv(g->OH, TH);
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
-  if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1>(p, s) : launch<4, 1>(p, s);
-  return g->ntaps == 3 ? launch<3, 2>(p, s) : launch<4, 2>(p, s);
+  p.raw = raw; p.yout = yout; p.mean = mean; p.rstd = rstd; p.coef = coef; p.relu = relu;
+  if (raw != nullptr) {
+    if (!mean || !rstd || !coef || (relu && !yout)) return AM_ERR_ARG;
+    if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, true>(p, s) : launch<4, 1, true>(p, s);
+    return g->ntaps == 3 ? launch<3, 2, true>(p, s) : launch<4, 2, true>(p, s);
+  }
+  if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, false>(p, s) : launch<4, 1, false>(p, s);
+  return g->ntaps == 3 ? launch<3, 2, false>(p, s) : launch<4, 2, false>(p, s);
 }

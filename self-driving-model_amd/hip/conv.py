@@ -448,6 +448,27 @@ class ConvBnAct(torch.autograd.Function):
                                  ptr(gp.grad) if direct else ptr(dgamma), ptr(bp.grad) if direct else ptr(dbeta), ptr(coef), cout, stream())
             if not ctx.use_batch:
                 coef[cout:].zero_()  # eval-mode BN: statistics are constants
+            fused_wgrad = False
+            if (s.first and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ctx.has_res and dtype == torch.float16
+                    and not (b is not None and ctx.needs_input_grad[2] and not ctx.use_batch)):
+                # first layer: nothing consumes the gradient w.r.t. the conv output except the weight gradient -- form it inside
+                # the wgrad kernel's tile load instead of writing and re-reading it (am_conv_wgrad_bn)
+                import ctypes
+                ktot = g.ntaps * g.krun
+                dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
+                try:
+                    _timed("conv_wgrad", 2.0 * P * s.cin * s.k * s.k * cout,
+                           lambda: L.am_conv_wgrad_bn(ctypes.byref(g), code, ptr(x), ptr(dy), ptr(y) if cfg.relu else None, ptr(raw), ptr(mean),
+                                                      ptr(rstd), ptr(coef), int(cfg.relu), inv, ptr(dwp), stream()))
+                    fused_wgrad = True
+                except RuntimeError as e:
+                    if "UNSUPPORTED" not in str(e):
+                        raise
+            if fused_wgrad:
+                dw = unpack_wgrad(dwp, s, dtype)
+                if b is not None and ctx.needs_input_grad[2]:
+                    db = torch.zeros_like(b)  # conv bias feeding a train-mode BN has an exactly zero gradient
+                return None, dw, db, dgamma, dbeta, None, None, None
             dz = torch.empty_like(dy)
             dres_t = torch.empty_like(dy) if (ctx.has_res and ctx.needs_input_grad[5]) else None
             L.am_bn_bwd_apply(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), int(cfg.relu),

@@ -500,3 +500,59 @@ def test_uint8_frames_boundary_matches_reference_preprocessing(norm):
                 assert torch.equal(a, b), (shape, dt)
     finally:
         runtime.set_input_normalization(None)
+
+
+@pytest.mark.parametrize("spec", [(64, 7, 3, False), (32, 5, 2, True)])
+def test_first_layer_weight_gradient_kernels_vs_torch(spec):
+    """Trainable first layer (conv [+bias] -> BatchNorm2d(train) -> ReLU on the image, trajectory_head.py:10-12 / ResNet stem)
+    in f16 at a size with ragged edge tiles: the space-to-depth weight-gradient kernel with the BatchNorm backward fused into
+    its tile load (am_conv_wgrad_bn) against torch autograd on the same f16-rounded operands, and against the generic
+    two-step path (AM_WGRAD_S2D=0 cannot be flipped in-process, so the generic kernel is called directly)."""
+    import ctypes
+    import torch.nn as nn
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    cout, k, pad, bias = spec
+    B, H, W = 2, 150, 214  # out 75 x 107: partial tiles in both directions
+    g = torch.Generator().manual_seed(10 + k)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = (torch.randn(cout, 3, k, k, generator=g) / (3 * k * k) ** 0.5)
+    bvec = 0.1 * torch.randn(cout, generator=g) if bias else None
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.2 * torch.randn(cout, generator=g)
+    probe = torch.randn(B, cout, (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1, generator=g)
+    # torch reference on the f16-rounded image / weight
+    wr = w.half().float().requires_grad_()
+    br = bvec.clone().requires_grad_() if bias else None
+    bn_ref = nn.BatchNorm2d(cout).train()
+    with torch.no_grad():
+        bn_ref.weight.copy_(gamma); bn_ref.bias.copy_(beta)
+    (F.relu(bn_ref(F.conv2d(img.half().float(), wr, br, stride=2, padding=pad))) * probe).sum().backward()
+    # HIP
+    s = hc.ConvSpec(3, cout, k, 2, pad, first=True)
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.to(_dev()).train()
+    wd = w.to(_dev()).requires_grad_()
+    bd = bvec.to(_dev()).requires_grad_() if bias else None
+    with runtime.precision(torch.float16, 1.0):
+        x = hops.image_to_s2d(img.to(_dev()), torch.float16)
+        y = hc.conv_bn_act(x, wd, bd, bn, True, None, hc._Cfg(s, hc.PackedWeights(), bn, True, 1.0), True)
+        yf = hops.NhwcToNchw.apply(y, cout, 1.0)
+        (yf * probe.to(_dev())).sum().backward()
+    assert rel_err(wd.grad, wr.grad) < 2e-2, rel_err(wd.grad, wr.grad)
+    assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 1e-2 and rel_err(bn.bias.grad, bn_ref.bias.grad) < 1e-2
+    if bias:
+        assert float(bd.grad.abs().max()) == 0.0  # a bias in front of a train-mode BN has an exactly zero gradient
+    # the plain (no BatchNorm) form of the same kernel: dW from an explicit conv-output gradient vs torch.nn.grad.conv2d_weight
+    with runtime.precision(torch.float16, 1.0):
+        x = hops.image_to_s2d(img.to(_dev()), torch.float16)
+        geo = hc.fwd_geom(s, B, x.shape[1], x.shape[2], 16, hc.channel_ld(cout, 2), 2, orig_hw=(H, W))
+        dz = torch.zeros(B, geo.OH, geo.OW, geo.ldo, dtype=torch.float16)
+        dz[..., :cout] = torch.randn(B, geo.OH, geo.OW, cout, generator=torch.Generator().manual_seed(3)).half()
+        a = torch.zeros(cout, geo.ntaps * geo.krun, device=_dev())
+        hc.conv_wgrad(geo, x, dz.to(_dev()), 1.0, a)
+        dw = hc.unpack_wgrad(a, s, torch.float16)
+    ref = torch.nn.grad.conv2d_weight(img.half().float(), w.shape, dz[..., :cout].float().permute(0, 3, 1, 2).contiguous(), stride=2, padding=pad)
+    assert rel_err(dw, ref) < 2e-3, rel_err(dw, ref)
