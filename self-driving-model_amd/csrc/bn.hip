@@ -15,11 +15,17 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, int nrep, double
   if (c >= C) return;
   float mean, rstd;
   if (training) {
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < nrep; ++r) {
-      s += stats[(size_t)r * 2 * C + c];
-      q += stats[(size_t)r * 2 * C + C + c];
+    // all replica loads in flight at once: issued one per iteration (runtime trip count, dependent adds) the 2*nrep L2 round
+    // trips were most of this tiny kernel's 8 us
+    double sv[AM_STATS_REPLICAS], qv[AM_STATS_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < AM_STATS_REPLICAS; ++r) {
+      sv[r] = r < nrep ? stats[(size_t)r * 2 * C + c] : 0.0;
+      qv[r] = r < nrep ? stats[(size_t)r * 2 * C + C + c] : 0.0;
     }
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int r = 0; r < AM_STATS_REPLICAS; ++r) { s += sv[r]; q += qv[r]; }
     const double m0 = s / count;
     double var = q / count - m0 * m0;
     if (var < 0.0) var = 0.0;
@@ -127,11 +133,15 @@ __global__ void bn_bwd_finalize_k(const double* __restrict__ sums, int nrep, dou
                                   float* __restrict__ dbeta, float* __restrict__ coef, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < nrep; ++r) {
-    s += sums[(size_t)r * 2 * C + c];
-    q += sums[(size_t)r * 2 * C + C + c];
+  double sv[AM_STATS_REPLICAS], qv[AM_STATS_REPLICAS];
+#pragma unroll
+  for (int r = 0; r < AM_STATS_REPLICAS; ++r) {
+    sv[r] = r < nrep ? sums[(size_t)r * 2 * C + c] : 0.0;
+    qv[r] = r < nrep ? sums[(size_t)r * 2 * C + C + c] : 0.0;
   }
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int r = 0; r < AM_STATS_REPLICAS; ++r) { s += sv[r]; q += qv[r]; }
   if (dgamma) dgamma[c] += (float)(q * gscale);
   if (dbeta) dbeta[c] += (float)(s * gscale);
   const float g = gamma ? gamma[c] : 1.f;
@@ -229,7 +239,7 @@ extern "C" int am_bn_finalize(const double* stats, int nrep, double count, const
                               int training, float* scale, float* shift, float* save_mean, float* save_rstd, int C,
                               am_stream_t stream) {
   if (C <= 0 || !scale || !shift) return AM_ERR_ARG;
-  if (training && (!stats || count <= 0.0)) return AM_ERR_ARG;
+  if (training && (!stats || count <= 0.0 || nrep > AM_STATS_REPLICAS)) return AM_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return AM_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), stats, nrep, count,
                      conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
@@ -281,7 +291,7 @@ extern "C" int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void*
 
 extern "C" int am_bn_bwd_finalize(const double* sums, int nrep, double count, const float* gamma, const float* rstd,
                                   float gscale, float* dgamma, float* dbeta, float* coef, int C, am_stream_t stream) {
-  if (!sums || !rstd || !coef || C <= 0 || count <= 0.0) return AM_ERR_ARG;
+  if (!sums || !rstd || !coef || C <= 0 || count <= 0.0 || nrep > AM_STATS_REPLICAS) return AM_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), sums, nrep, count, gamma, rstd, gscale, dgamma, dbeta, coef, C);
   AM_CHECK_LAUNCH();
   return AM_OK;
