@@ -87,6 +87,15 @@ int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w,
 int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
                         const float* shift, void* y, double* stats, am_stream_t stream);
 
+/* am_conv_gemm on relu(x * pre_scale[c] + pre_shift[c]): the BatchNorm(+ReLU) of the PRODUCING layer (scale / shift from
+ * am_bn_finalize, am_bn_apply's fp32 arithmetic) is applied while the input tile is staged in LDS, so that layer's normalised
+ * output never goes through HBM (ResNet BasicBlock conv1 -> bn1 -> relu -> conv2 with nothing else reading the middle tensor,
+ * torchvision resnet.py BasicBlock.forward as used by bdd_*_expert.py:9-11).  Zero padding applies to the transformed tensor.
+ * No bias / ReLU epilogue; `stats` as in am_conv_gemm.  Returns AM_ERR_UNSUPPORTED unless the layer is a dense 3x3 / stride 1 /
+ * pad 1, 64 -> 64 f16 convolution large enough for the weights-in-registers kernel (caller: am_bn_apply + am_conv_gemm). */
+int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
+                       const void* w, void* y, double* stats, am_stream_t stream);
+
 /* Diagnostic (bench.py roofline leg): which kernel the last am_conv_gemm / am_conv_first_fused call of this process launched.
  * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 conv3x3_c64n64_wreg_k,
  * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k. */

@@ -656,6 +656,18 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
   return launch_wgrad<float, 64, 4>(p, s);
 }
 
+int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                                  const float* bias, int relu, void* y, double* stats, hipStream_t s);  // conv_patch3.hip
+
+extern "C" int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
+                                  const void* w, void* y, double* stats, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !w || !y || !pre_scale || !pre_shift) return AM_ERR_ARG;
+  if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
+  return am_conv3x3_c64n64_duo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, y, stats, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,
                                 const float* mean, const float* rstd, const float* coef, int relu, float scale, float* dw,
                                 am_stream_t stream) {

@@ -43,6 +43,10 @@ struct Patch3Params {
   int B, H, W, ldi, x_coff, ldo, y_coff;
   int tiles_y, tiles_x, ntiles;
   unsigned x_bytes, w_bytes, y_bytes;
+  // optional input transform relu(x * pre_scale[c] + pre_shift[c]) applied to the staged patch: the BatchNorm + ReLU of the
+  // producing layer (bn.hip bn_apply_k arithmetic, fp32), so its normalised output never goes through HBM
+  const float* pre_scale;
+  const float* pre_shift;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -97,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   const int row_bytes = p.W * p.ldi * 2, pix_bytes = p.ldi * 2;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   char* const gpatch = smem;
+  float* const aff = reinterpret_cast<float*>(smem + PATCH_BYTES + 4 * STG_WAVE);  // [2][64] scale, shift (input transform)
+  const bool pre = p.pre_scale != nullptr;
+  if (pre && tid < 128) aff[tid] = tid < 64 ? p.pre_scale[tid] : p.pre_shift[tid - 64];
 
   auto issue_patch = [&](int tile, int buf) {
     const int img = tile / tiles_per_img;
@@ -124,6 +131,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     }
   };
 
+  // Input transform of the patch of `tile` in buffer `buf`: every lane rewrites exactly the 16-byte chunks its own DMA
+  // instructions delivered (call after this wave's vmcnt wait, before the barrier that publishes the patch).  Pixels outside
+  // the image stay zero (the convolution's padding applies to the TRANSFORMED tensor).
+  auto transform_patch = [&](int tile, int buf) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+    char* dst = gpatch + buf * PATCH_SLOT + w4 * (IPW * 1024);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      if (w4 * IPW + i < NINST) {
+        const int q = (w4 * IPW + i) * 64 + ln;
+        const int pix = q / 9, cc = q - pix * 9;
+        const int prow = pix / PW, pcol = pix - prow * PW;
+        if (cc < 8 && pix < NPIX && (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pcol) < (unsigned)p.W) {
+          half8_t* slot = reinterpret_cast<half8_t*>(dst + i * 1024 + ln * 16);
+          const half8_t v = *slot;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + cc * 8), s1 = *reinterpret_cast<const f32x4*>(aff + cc * 8 + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + 64 + cc * 8), h1 = *reinterpret_cast<const f32x4*>(aff + 64 + cc * 8 + 4);
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (half_t)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
+            o[4 + e] = (half_t)fmaxf((float)v[4 + e] * s1[e] + h1[e], 0.f);
+          }
+          *slot = o;
+        }
+      }
+    }
+  };
+
   // per-lane partial BN sums of the lane's 16 channels, folded across pixel lanes at the end
   f32x16 ssum, ssq;
 #pragma unroll
@@ -143,6 +184,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   int tile = xcd * chunk + (int)(blockIdx.x >> 3);
   if (tile < tend) issue_patch(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pre) {
+    __syncthreads();  // the scale/shift table is in LDS
+    if (tile < tend) transform_patch(tile, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (tile + per_xcd < tend) issue_patch(tile + per_xcd, 1);
@@ -186,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     // next goes into the buffer just read, two tiles ahead of its use (an LDS-DMA from HBM takes longer than one MFMA
     // phase under load).  Raw barrier + asm wait: __syncthreads() would do, the explicit form documents what is ordered.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pre && tile + per_xcd < tend) {
+      transform_patch(tile + per_xcd, buf ^ 1);  // this wave's share of the next patch has landed: rewrite it in place
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (tile + 2 * per_xcd < tend) issue_patch(tile + 2 * per_xcd, buf);
@@ -273,8 +323,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
 
 // Returns AM_ERR_UNSUPPORTED unless the geometry is exactly a dense 3x3 / stride 1 / pad 1, 64 -> 64 f16 convolution
 // (forward packing, tap order kh-major) without bias / ReLU epilogue, over a tensor small enough for 30-bit offsets.
+int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                                  const float* bias, int relu, void* y, double* stats, hipStream_t s);
+
 int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
                               double* stats, hipStream_t s) {
+  return am_conv3x3_c64n64_duo_pre_f16(g, x, nullptr, nullptr, w, bias, relu, y, stats, s);
+}
+
+// pre_scale / pre_shift (both or neither): the convolution runs on relu(x * pre_scale[c] + pre_shift[c]).
+int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                                  const float* bias, int relu, void* y, double* stats, hipStream_t s) {
   using namespace amp3;
   if (g->ntaps != 9 || g->krun != 64 || g->N != 64 || g->pix_shift != 31) return AM_ERR_UNSUPPORTED;
   if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
@@ -293,6 +352,7 @@ int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* 
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
   p.x_bytes = (unsigned)x_bytes;
   p.w_bytes = 64 * WROW;
+  p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.y_bytes = (unsigned)y_bytes;
   static bool attr_done = false;
   if (!attr_done) {

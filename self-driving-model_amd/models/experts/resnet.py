@@ -33,6 +33,12 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):  # x: NHWC
+        if self.downsample is None and self.conv1.in_channels == 64 and not torch.is_grad_enabled() or (
+                self.downsample is None and self.conv1.in_channels == 64 and not self.conv1.weight.requires_grad):
+            y = hconv.fused_basic_block_c64(x, self.conv1.weight, self.bn1, self.conv1._packed, self.conv2.weight, self.bn2,
+                                            self.conv2._packed)  # frozen layer1 block: bn1 + ReLU live inside conv2's input staging
+            if y is not None:
+                return y
         idn = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
         y = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         return conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idn)

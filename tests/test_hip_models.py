@@ -833,3 +833,30 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(tot, tot_r, rtol=1e-4, atol=1e-6); close(cls, cls_r, rtol=1e-4, atol=1e-6); close(box, box_r, rtol=1e-4, atol=1e-6)
     close(lg.grad, lg_r.grad, rtol=1e-3, atol=1e-6)
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
+
+
+def test_frozen_basic_block_fused_bn_matches_unfused():
+    """Frozen ResNet layer1 block in train-mode BN, f16: bn1 + ReLU applied inside conv2's input staging (am_conv_gemm_prebn)
+    vs the unfused conv -> bn_apply -> conv sequence -- same output (f16 rounding of identical fp32 arithmetic; statistics
+    accumulate in a different order) and the same running-statistics updates, at a size with ragged edge tiles."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.models.experts.resnet import BasicBlock
+    dev = _dev()
+    x = (seeded_tensor((2, 181, 190, 64), 5) * 0.7).to(dev).half()  # >= 64 k pixels: the weights-in-registers kernel
+    outs = {}
+    for fused in (False, True):
+        blk = seed_module_(BasicBlock(64, 64, 1), 17).to(dev).train()
+        for p_ in blk.parameters():
+            p_.requires_grad = False
+        hc.FUSE_BLOCK_BN = fused
+        with runtime.precision(torch.float16, 1.0):
+            runtime.begin_step(dev)
+            y = blk(x)
+            hc.flush_bn_counters()
+        outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
+    hc.FUSE_BLOCK_BN = True
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    for k, v in outs[False][1].items():
+        close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
+    assert int(outs[True][1]["bn1.num_batches_tracked"]) == 1 and int(outs[True][1]["bn2.num_batches_tracked"]) == 1
