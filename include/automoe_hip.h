@@ -136,6 +136,12 @@ int am_bn_finalize(const double* stats, int nrep, double count, const float* con
                    am_stream_t stream);
 int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                 int relu, void* y, int ldy, long long P, int C, am_stream_t stream);
+/* am_bn_apply whose residual is itself a raw conv output normalised on the fly (the downsample branch of a strided
+ * BasicBlock: y = relu(bn2(conv2) + bn_d(conv_d)), torchvision resnet.py BasicBlock.forward): res' = round(res*res_scale +
+ * res_shift) as a separate am_bn_apply pass would have stored it.  res_scale/res_shift both NULL: am_bn_apply. */
+int am_bn_apply2(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
+                 const float* res_scale, const float* res_shift, int relu, void* y, int ldy, long long P, int C,
+                 am_stream_t stream);
 int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
                      const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
                      am_stream_t stream);

@@ -54,9 +54,10 @@ struct Vec16 {
   T v[N];
 };
 
-template <typename T>
+template <typename T, bool RAFF>
 __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                  const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                   int relu, T* __restrict__ y, int ldy, long long P, int C) {
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;  // chunks per pixel row
@@ -67,11 +68,28 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
     Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
     Vec16<T> rv;
     if (res) rv = *reinterpret_cast<const Vec16<T>*>(res + pix * ldr + c0);
+    // per-channel constants of this chunk as 16-byte loads (c0 is a multiple of E): left to itself hipcc issues them one dword
+    // at a time with a wait in front of each use
+    float sc[E], sh[E], rs[E], rh[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      *reinterpret_cast<f32x4*>(sc + e) = *reinterpret_cast<const f32x4*>(scale + c0 + e);
+      *reinterpret_cast<f32x4*>(sh + e) = *reinterpret_cast<const f32x4*>(shift + c0 + e);
+      if (RAFF) {
+        *reinterpret_cast<f32x4*>(rs + e) = *reinterpret_cast<const f32x4*>(rscale + c0 + e);
+        *reinterpret_cast<f32x4*>(rh + e) = *reinterpret_cast<const f32x4*>(rshift + c0 + e);
+      }
+    }
     Vec16<T> out;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      float v = am_to_f32(xv.v[e]) * scale[c0 + e] + shift[c0 + e];
-      if (res) v += am_to_f32(rv.v[e]);
+      float v = am_to_f32(xv.v[e]) * sc[e] + sh[e];
+      if (res) {
+        // a raw residual (the downsample conv's output) is normalised here, rounded to T first like the tensor a separate
+        // am_bn_apply pass would have written
+        const float r = am_to_f32(rv.v[e]);
+        v += RAFF ? am_to_f32(am_from_f32<T>(r * rs[e] + rh[e])) : r;
+      }
       if (relu) v = fmaxf(v, 0.f);
       out.v[e] = am_from_f32<T>(v);
     }
@@ -250,8 +268,19 @@ extern "C" int am_bn_finalize(const double* stats, int nrep, double count, const
 
 #define AM_EW_CHECK(C, ld, es) (((C) * (es)) % 16 != 0 || ((ld) * (es)) % 16 != 0)
 
+extern "C" int am_bn_apply2(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
+                            const float* res_scale, const float* res_shift, int relu, void* y, int ldy, long long P, int C,
+                            am_stream_t stream);
+
 extern "C" int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                            int relu, void* y, int ldy, long long P, int C, am_stream_t stream) {
+  return am_bn_apply2(dtype, x, ldx, scale, shift, res, ldr, nullptr, nullptr, relu, y, ldy, P, C, stream);
+}
+
+extern "C" int am_bn_apply2(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
+                            const float* res_scale, const float* res_shift, int relu, void* y, int ldy, long long P, int C,
+                            am_stream_t stream) {
+  if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return AM_ERR_ARG;
   const int es = dtype == AM_F16 ? 2 : 4;
   if ((dtype != AM_F16 && dtype != AM_F32) || !x || !y || !scale || !shift || P < 0 || C <= 0) return AM_ERR_ARG;
   if (AM_EW_CHECK(C, ldx, es) || (ldy * es) % 16 != 0 || (res && (ldr * es) % 16 != 0)) return AM_ERR_ARG;
@@ -259,9 +288,15 @@ extern "C" int am_bn_apply(int dtype, const void* x, int ldx, const float* scale
   const int grid = ew_grid(P * (C * es / 16));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16)
-    hipLaunchKernelGGL(bn_apply_k<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, scale, shift, (const half_t*)res, ldr, relu, (half_t*)y, ldy, P, C);
+    {
+    if (res_scale) hipLaunchKernelGGL((bn_apply_k<half_t, true>), dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, scale, shift, (const half_t*)res, ldr, res_scale, res_shift, relu, (half_t*)y, ldy, P, C);
+    else hipLaunchKernelGGL((bn_apply_k<half_t, false>), dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, scale, shift, (const half_t*)res, ldr, res_scale, res_shift, relu, (half_t*)y, ldy, P, C);
+  }
   else
-    hipLaunchKernelGGL(bn_apply_k<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, scale, shift, (const float*)res, ldr, relu, (float*)y, ldy, P, C);
+    {
+    if (res_scale) hipLaunchKernelGGL((bn_apply_k<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, scale, shift, (const float*)res, ldr, res_scale, res_shift, relu, (float*)y, ldy, P, C);
+    else hipLaunchKernelGGL((bn_apply_k<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, scale, shift, (const float*)res, ldr, res_scale, res_shift, relu, (float*)y, ldy, P, C);
+  }
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

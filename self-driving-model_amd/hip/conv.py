@@ -615,3 +615,57 @@ def fused_basic_block_c64(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, 
     y = torch.empty_like(x)
     L.am_bn_apply(AM_F16, ptr(raw2), 64, ptr(sc2), ptr(sh2), ptr(x), 64, 1, ptr(y), 64, P, 64, stream())
     return y
+
+
+def _conv_stats_nograd(x, w, s: ConvSpec, cache: PackedWeights):
+    """Raw convolution output + BatchNorm batch statistics of a frozen layer (no autograd bookkeeping)."""
+    B, IH, IW, ldi = x.shape
+    ldo = channel_ld(s.cout, x.element_size())
+    g = fwd_geom(s, B, IH, IW, ldi, ldo, x.element_size())
+    raw = (torch.zeros if ldo != s.cout else torch.empty)((B, g.OH, g.OW, ldo), dtype=x.dtype, device=x.device)
+    stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * s.cout, x.device)
+    conv_gemm(g, x, cache.get_fwd(w, s, x.dtype), None, False, raw, stats, k_real=s.cin * s.k * s.k)
+    return raw, stats, B * g.OH * g.OW
+
+
+def _bn_finalize_nograd(bn, stats, P: int, C: int):
+    scale = torch.empty(C, dtype=torch.float32, device=stats.device)
+    shift = torch.empty_like(scale)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    upd = bn.track_running_stats and bn.running_mean is not None
+    _L().am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
+                        ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum), float(bn.eps), 1,
+                        ptr(scale), ptr(shift), None, None, C, stream())
+    if upd and bn.num_batches_tracked is not None:
+        PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+    return scale, shift
+
+
+@torch.no_grad()
+def fused_basic_block_down(x, blk):
+    """Strided ResNet BasicBlock (3x3/s2 conv1, 1x1/s2 downsample shortcut) of a FROZEN trunk in train-mode BatchNorm:
+        y = relu(bn2(conv2(relu(bn1(conv1(x))))) + bn_d(conv_d(x)))
+    with the shortcut's BatchNorm applied inside the final normalise + add + ReLU pass (am_bn_apply2) instead of a pass of
+    its own.  `blk` is models.experts.resnet.BasicBlock.  Returns None when the case is not covered."""
+    mods = (blk.conv1, blk.bn1, blk.conv2, blk.bn2, blk.downsample[0], blk.downsample[1])
+    if not (FUSE_BLOCK_BN and os.environ.get("AM_FUSE_DOWN", "1") != "0" and blk.bn1.training and blk.bn2.training and blk.downsample[1].training):
+        return None
+    if any(p.requires_grad for m in mods for p in m.parameters()) or any(m.bias is not None for m in (blk.conv1, blk.conv2, blk.downsample[0])):
+        return None
+    L = _L()
+    code = dt_code(x.dtype)
+    C = blk.conv1.spec.cout
+    raw1, st1, P = _conv_stats_nograd(x, blk.conv1.weight, blk.conv1.spec, blk.conv1._packed)
+    raw_d, st_d, _ = _conv_stats_nograd(x, blk.downsample[0].weight, blk.downsample[0].spec, blk.downsample[0]._packed)
+    ld = raw1.shape[-1]
+    if ld != C:
+        return None
+    sc1, sh1 = _bn_finalize_nograd(blk.bn1, st1, P, C)
+    y1 = torch.empty_like(raw1)
+    L.am_bn_apply(code, ptr(raw1), ld, ptr(sc1), ptr(sh1), None, 0, 1, ptr(y1), ld, P, C, stream())
+    raw2, st2, _ = _conv_stats_nograd(y1, blk.conv2.weight, blk.conv2.spec, blk.conv2._packed)
+    sc2, sh2 = _bn_finalize_nograd(blk.bn2, st2, P, C)
+    sc_d, sh_d = _bn_finalize_nograd(blk.downsample[1], st_d, P, C)
+    y = torch.empty_like(raw2)
+    L.am_bn_apply2(code, ptr(raw2), ld, ptr(sc2), ptr(sh2), ptr(raw_d), ld, ptr(sc_d), ptr(sh_d), 1, ptr(y), ld, P, C, stream())
+    return y

@@ -39,6 +39,10 @@ class BasicBlock(nn.Module):
                                             self.conv2._packed)  # frozen layer1 block: bn1 + ReLU live inside conv2's input staging
             if y is not None:
                 return y
+        if self.downsample is not None and not self.conv1.weight.requires_grad:
+            y = hconv.fused_basic_block_down(x, self)  # frozen strided block: the shortcut's BN rides in the final add + ReLU pass
+            if y is not None:
+                return y
         idn = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
         y = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         return conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idn)

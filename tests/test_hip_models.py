@@ -860,3 +860,31 @@ def test_frozen_basic_block_fused_bn_matches_unfused():
     for k, v in outs[False][1].items():
         close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
     assert int(outs[True][1]["bn1.num_batches_tracked"]) == 1 and int(outs[True][1]["bn2.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_frozen_strided_block_fused_shortcut_bn_matches_unfused(dtype):
+    """Frozen strided BasicBlock in train-mode BN: the downsample shortcut's BatchNorm applied inside the final normalise +
+    add + ReLU pass (am_bn_apply2) vs the unfused sequence: identical arithmetic (the shortcut is rounded to the activation
+    type before the add in both), same running-statistics updates."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.models.experts.resnet import BasicBlock
+    dev = _dev()
+    x = (seeded_tensor((2, 37, 50, 64), 6) * 0.7).to(dev).to(dtype)
+    outs = {}
+    for fused in (False, True):
+        blk = seed_module_(BasicBlock(64, 128, 2), 19).to(dev).train()
+        for p_ in blk.parameters():
+            p_.requires_grad = False
+        hc.FUSE_BLOCK_BN = fused
+        with runtime.precision(dtype, 1.0):
+            runtime.begin_step(dev)
+            y = blk(x)
+            hc.flush_bn_counters()
+        outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
+    hc.FUSE_BLOCK_BN = True
+    assert y.shape == (2, 19, 25, 128)
+    assert rel_err(outs[True][0], outs[False][0]) < (2e-3 if dtype == torch.float16 else 1e-5)
+    for k, v in outs[False][1].items():
+        close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
