@@ -618,7 +618,7 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     // into 64 channels) stays on the register-staged kernel
     static int ring_all = -1;
     if (ring_all < 0) { const char* e = getenv("AM_CONV_RING_ALL"); ring_all = e ? atoi(e) : 1; }
-    if ((long long)p.M <= 65536 || g->N >= 256 || ring_all) {
+    if ((long long)p.M <= 65536 || g->N >= 256 || (ring_all && g->N > 64)) {
       rc = am_conv_gemm2_f16(g, x, w, bias, relu, y, stats, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }

@@ -323,10 +323,7 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
 int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                      hipStream_t s) {
   using namespace amr;
-  static int small_n = -1;
-  if (small_n < 0) { const char* e = getenv("AM_RING_SMALLN"); small_n = e ? atoi(e) : 1; }
-  if (g->ntaps <= 0 || g->ntaps > RING_MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0) return AM_ERR_UNSUPPORTED;
-  if (g->N <= 64 && !(small_n && (long long)g->B * g->MH * g->MW >= 256 * 512)) return AM_ERR_UNSUPPORTED;
+  if (g->ntaps <= 0 || g->ntaps > RING_MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0 || g->N <= 64) return AM_ERR_UNSUPPORTED;
   const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
   const long long Ktot = (long long)g->ntaps * g->krun;
   const long long w_bytes = (long long)am_conv_npad(g->N) * Ktot * 2;
@@ -345,9 +342,6 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   for (int t = 0; t < RING_MAX_TAPS; ++t)
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
   const long long mt256 = (p.M + 255) / 256;
-  // N <= 64 over a large M (policy layers and their input gradients): memory-bound shapes -- a 256x64 tile per 4-wave
-  // workgroup (N = 32 runs as 64 with the missing weight rows read as zeros), two or more workgroups per CU
-  if (g->N <= 64) return launch_ring<256, 64, 4, 1>(p, s);
   if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) return launch_ring<256, 256, 2, 4>(p, s);
   static int n128 = -1;
   if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
