@@ -34,6 +34,54 @@ struct S2dParams {
   double* stats;      // modes 0, 1: [16][2][N]
   int B, IH, IW, OH, OW, ldo, y_coff, off0, relu;
   int tiles_y, tiles_x, ntiles, N;
+  unsigned x_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+constexpr unsigned OOB = 0x80000000u;  // at or above every image's byte size (checked by the host entry)
+
+// 16 bytes per lane from the raw buffer (base, bytes) into LDS at dst + lane*16; offsets at or past `bytes` deliver zeros.
+__device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes, char* dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                           (lds_ptr)dst, 16, voff, 0, 0, 0);
+}
+
+// Input patch loader: PH x PW pixels x 32 B as 1 KiB LDS-DMA pieces dealt round-robin to the NWAVES waves.  Which patch
+// pixel and 16-byte half a lane fetches never changes, so its row / column / byte offset inside the patch are computed
+// once; per tile a piece costs two adds, two compares and a select (pixels outside the image ask for an out-of-range
+// offset: the buffer load writes the zero padding).
+template <int PH, int PW, int NWAVES>
+struct PatchLoader {
+  static constexpr int PATCH_BYTES = PH * PW * CB;
+  static constexpr int PATCH_INST = (PATCH_BYTES + 1023) / 1024;
+  static constexpr int NI = (PATCH_INST + NWAVES - 1) / NWAVES;
+  int prow[NI], pcol[NI];
+  unsigned loff[NI];
+  __device__ __forceinline__ void init(int wid, int lane, int IW) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int q = (wid + k * NWAVES) * 64 + lane;
+      const int pidx = q >> 1, cpos = q & 1;
+      const int c = cpos ^ ((pidx >> 3) & 1);
+      const int pr = pidx / PW, pc = pidx - pr * PW;
+      prow[k] = q < PATCH_BYTES / 16 ? pr : (1 << 28);  // past the patch: never inside the image
+      pcol[k] = pc;
+      loff[k] = (unsigned)((pr * IW + pc) * CB + c * 16);
+    }
+  }
+  // patch whose pixel (0, 0) is image pixel (iy0, ix0) of image img
+  __device__ __forceinline__ void issue(const void* x, unsigned x_bytes, int IH, int IW, int img, int iy0, int ix0, char* dst,
+                                        int wid) const {
+    const int base = ((img * IH + iy0) * IW + ix0) * CB;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int inst = wid + k * NWAVES;
+      if (inst < PATCH_INST) {
+        const bool ok = (unsigned)(iy0 + prow[k]) < (unsigned)IH && (unsigned)(ix0 + pcol[k]) < (unsigned)IW;
+        buffer_to_lds16(x, x_bytes, dst + inst * 1024, ok ? (unsigned)base + loff[k] : OOB);
+      }
+    }
+  }
 };
 
 template <int TAPS, int NT, int MODE>
@@ -58,7 +106,8 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
   const char* __restrict__ x = static_cast<const char*>(p.x);
   const char* __restrict__ w = static_cast<const char*>(p.w);
   half_t* __restrict__ y = static_cast<half_t*>(p.y);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* zl = reinterpret_cast<const char*>(g_zero_line);
   const int ktot_bytes = TAPS * 64 * 2;            // packed global row: taps x (4 px x 16 ch) halves
 
@@ -76,23 +125,13 @@ __global__ __launch_bounds__(256) void conv_s2d_k(const S2dParams p) {
                                      (__attribute__((address_space(3))) void*)(Wl + inst * 1024), 16, 0, 0);
   }
 
+  PatchLoader<PH, PW, 4> loader;
+  loader.init(wid, lane, p.IW);
   auto issue_patch = [&](int tile, int buf) {
     const int img = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - img * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const int iy0 = ty * TH + p.off0, ix0 = tx * TW + p.off0;
-    char* dst = patch0 + buf * PATCH_SLOT;
-    for (int inst = wid; inst < PATCH_INST; inst += 4) {
-      const int q = inst * 64 + lane;
-      const int pidx = q >> 1, cpos = q & 1;
-      const int c = cpos ^ ((pidx >> 3) & 1);
-      const int prow = pidx / PW, pcol = pidx - prow * PW;
-      const int iy = iy0 + prow, ix = ix0 + pcol;
-      const bool ok = q < PATCH_BYTES / 16 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const char* src = ok ? x + ((long long)(img * p.IH + iy) * p.IW + ix) * CB + c * 16 : zl;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, 0, 0);
-    }
+    loader.issue(p.x, p.x_bytes, p.IH, p.IW, img, ty * TH + p.off0, tx * TW + p.off0, patch0 + buf * PATCH_SLOT, wid);
   };
 
   int tile = blockIdx.x;
@@ -301,8 +340,78 @@ int launch_s2d(const S2dParams& p, hipStream_t s) {
 // 8 waves, conv tile 16 x 32 (wave w: rows 2w, 2w+1) = the 15 x 31 conv outputs behind a 7 x 15 pooled tile (+1 spare
 // row / column); neighbouring tiles recompute the one-pixel overlap (27 % extra MFMA work on a layer that is far from
 // MFMA-bound) instead of exchanging halos.  Post-ReLU values are >= 0 and every pooling window holds at least one
-// in-image conv output, so out-of-image positions are staged as 0 (equivalent to max-pool's -inf padding).
+// in-image conv output, so out-of-image positions count as 0 (equivalent to max-pool's -inf padding).
+//
+// The MFMAs run transposed (A = weights, B = pixels): a lane owns ONE conv pixel (column lane & 31 of its wave's two
+// rows) and, per accumulator register quad, four consecutive channels.  The whole epilogue therefore stays in
+// registers as packed halves: BN + ReLU (packed f32 mul/add, v_cvt_pk_f16_f32, v_pk_max_f16), the vertical maximum of
+// the wave's own two rows, ONE row exchanged with the next wave through LDS (pooled row w needs conv rows 2w, 2w+1 and
+// 2w+2, the last one is wave w+1's first), and the horizontal 3-window as two whole-wave DPP shifts.  Only the pooled
+// row goes through a small per-wave staging strip to leave as 16-byte stores.  One workgroup barrier per tile (shared
+// with the patch ring); the first version staged the whole 16 x 32 x 64 map and re-read it nine times.
 constexpr int PTH = 7, PTW = 15, CTH = 16, CTW = 32;
+constexpr int XPITCH = 144;                      // bytes per staged pixel (64 channels + 16): conflict-free 8-byte accesses
+constexpr int XROW = CTW * XPITCH;               // one exchanged conv row
+constexpr int OROW = ((PTW * XPITCH + 255) / 256) * 256;  // one pooled row
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// lane i <- lane i + 1 (whole-wave shift, DPP wave_shl:1; lane 63 gets 0)
+__device__ __forceinline__ unsigned wave_next(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2_t, a), __builtin_bit_cast(half2_t, b)));
+}
+
+// K-steps [S0, S1) of one conv tile (one k16 step per tap), transposed MFMAs (A = weights, B = pixels), software-pipelined
+// like conv_s2d_k: the fragment reads of step s are issued while the MFMAs of step s-2 run.  S0 == 0 starts from zero.
+template <int TAPS, int S0, int S1>
+__device__ __forceinline__ void pool_mfma(const char* pt, const char* Wl, int wid, int lane, f32x16 (&acc)[2][2]) {
+  constexpr int NT = 2;
+  constexpr int PW = CTW + TAPS - 1;
+  constexpr int WPITCH = TAPS * TAPS * 32 + 16;
+  const int rx = lane & 31, kg = lane >> 5;
+  half8_t fa[3][2], fb[3][NT];
+#pragma unroll
+  for (int s = S0; s < S1 + 2; ++s) {
+    if (s >= S0 + 2) {
+      if (s == S1 + 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0xC47F);              // lgkmcnt(4): the reads of step s-1 stay in flight
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s < S1) {
+      const int i = s / TAPS, j = s - i * TAPS;
+      const int pid0 = (2 * wid + i) * PW + rx + j;
+      const int pid1 = pid0 + PW;
+      fa[s % 3][0] = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((kg ^ ((pid0 >> 3) & 1)) << 4));
+      fa[s % 3][1] = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((kg ^ ((pid1 >> 3) & 1)) << 4));
+      const char* bb = Wl + rx * WPITCH + s * 32 + kg * 16;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) fb[s % 3][tn] = *reinterpret_cast<const half8_t*>(bb + tn * 32 * WPITCH);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s >= S0 + 2) {
+      const int c = (s - 2) % 3;
+      if (s == 2) {  // S0 == 0: the first step starts from the constant zero, no accumulator clears
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][0], z, 0, 0, 0);
+          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][1], z, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][0], acc[0][tn], 0, 0, 0);
+          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[c][tn], fa[c][1], acc[1][tn], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 template <int TAPS>
 __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int POH, int POW, int ptiles_y, int ptiles_x) {
@@ -315,19 +424,22 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
   constexpr int WPITCH = KSTEPS * 32 + 16;
   constexpr int WCH = WPITCH / 16;
   constexpr int W_BYTES = ((NCH * WPITCH + 1023) / 1024) * 1024;
-  constexpr int SPX = NCH * 2;  // staging: [16 rows][32 px][64 ch] halves, 128 B per pixel
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Wl = smem;
   char* patch0 = smem + W_BYTES;
-  char* stg = smem + W_BYTES + 2 * PATCH_SLOT;
+  char* xbuf = smem + W_BYTES + 2 * PATCH_SLOT;  // [2 tile parities][waves 1..7][32 px][XPITCH]: first conv row of each wave
+  char* obuf = xbuf + 2 * 7 * XROW;              // [waves 0..6][OROW]: pooled row staging, private to the wave
+  float* bnc = reinterpret_cast<float*>(obuf + 7 * OROW);  // [scale 64][shift 64]
 
   const char* __restrict__ x = static_cast<const char*>(p.x);
   const char* __restrict__ w = static_cast<const char*>(p.w);
   half_t* __restrict__ y = static_cast<half_t*>(p.y);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* zl = reinterpret_cast<const char*>(g_zero_line);
   const int ktot_bytes = TAPS * 64 * 2;
+  if (tid < 2 * NCH) bnc[tid] = tid < NCH ? p.scale[tid] : p.shift[tid - NCH];
 
   for (int inst = wid; inst < W_BYTES / 1024; inst += 8) {
     const int q = inst * 64 + lane;
@@ -347,22 +459,12 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
     pty = rem / ptiles_x;
     ptx = rem - pty * ptiles_x;
   };
+  PatchLoader<PH, PW, 8> loader;
+  loader.init(wid, lane, p.IW);
   auto issue_patch = [&](int tile, int buf) {
     int img, pty, ptx;
     tile_origin(tile, img, pty, ptx);
-    const int iy0 = 2 * PTH * pty - 1 + p.off0, ix0 = 2 * PTW * ptx - 1 + p.off0;
-    char* dst = patch0 + buf * PATCH_SLOT;
-    for (int inst = wid; inst < PATCH_INST; inst += 8) {
-      const int q = inst * 64 + lane;
-      const int pidx = q >> 1, cpos = q & 1;
-      const int c = cpos ^ ((pidx >> 3) & 1);
-      const int prow = pidx / PW, pcol = pidx - prow * PW;
-      const int iy = iy0 + prow, ix = ix0 + pcol;
-      const bool ok = q < PATCH_BYTES / 16 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const char* src = ok ? x + ((long long)(img * p.IH + iy) * p.IW + ix) * CB + c * 16 : zl;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, 0, 0);
-    }
+    loader.issue(p.x, p.x_bytes, p.IH, p.IW, img, 2 * PTH * pty - 1 + p.off0, 2 * PTW * ptx - 1 + p.off0, patch0 + buf * PATCH_SLOT, wid);
   };
 
   int tile = blockIdx.x;
@@ -370,84 +472,124 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  float sc[NT], sh[NT];
-#pragma unroll
-  for (int tn = 0; tn < NT; ++tn) {
-    sc[tn] = p.scale[tn * 32 + (lane & 31)];
-    sh[tn] = p.shift[tn * 32 + (lane & 31)];
-  }
   const int rx = lane & 31, kg = lane >> 5;
-  int buf = 0;
+  // Second half of a tile's epilogue (needs the row exchanged at the barrier): vertical window with the next wave's
+  // first row, horizontal window by DPP, pooled row out through the wave's staging strip.
+  auto pool_out = [&](int t, int tbuf, const half4_t (&v)[NT][4]) {
+    if (wid >= 7) return;
+    int img, pty, ptx;
+    tile_origin(t, img, pty, ptx);
+    const char* xn = xbuf + (tbuf * 7 + wid) * XROW + rx * XPITCH + 8 * kg;  // wave wid+1's first row = conv row 2*wid + 2
+    char* ow = obuf + wid * OROW;
+    u32x2 m[NT][4];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const half4_t nb = *reinterpret_cast<const half4_t*>(xn + tn * 64 + q * 16);
+        m[tn][q] = __builtin_bit_cast(u32x2, __builtin_elementwise_max(v[tn][q], nb));  // vertical 3-window
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          unsigned u = m[tn][q][e];
+          u = pkmax(u, wave_next(u));  // columns rx, rx+1
+          u = pkmax(u, wave_next(u));  // columns rx .. rx+2 (rx even: pooled column rx/2)
+          m[tn][q][e] = u;
+        }
+      }
+    if (!(rx & 1) && rx < 2 * PTW) {
+      char* od = ow + (rx >> 1) * XPITCH + 8 * kg;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(od + tn * 64 + q * 16) = m[tn][q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int oy = pty * PTH + wid;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = it * 64 + lane;
+      const int ppx = e >> 3, c8 = e & 7;
+      const int ox = ptx * PTW + ppx;
+      if (ppx < PTW && oy < POH && ox < POW)
+        *reinterpret_cast<uint4*>(y + ((long long)(img * POH + oy) * POW + ox) * p.ldo + p.y_coff + c8 * 8) =
+            *reinterpret_cast<const uint4*>(ow + ppx * XPITCH + c8 * 16);
+    }
+  };
+
+  // Waves 4..7 share their SIMDs with waves 0..3.  All eight run the same per-tile program between two barriers, so
+  // left alone the partners would reach their MFMA phases and their (VALU-only) epilogues together.  The previous tile's
+  // pool_out is therefore placed differently: waves 0..3 run it right after the barrier, before their MFMAs; waves 4..7
+  // start their MFMAs at once and run it between the two halves of the tap loop.
+  const bool late = wid >= 4;
+  int buf = 0, ptile = -1;
+  half4_t v[NT][4];
   for (; tile < p.ntiles; tile += gridDim.x) {
+    if (!late && ptile >= 0) pool_out(ptile, buf ^ 1, v);
     const int next = tile + gridDim.x;
     if (next < p.ntiles) issue_patch(next, buf ^ 1);
     const char* pt = patch0 + buf * PATCH_SLOT;
     f32x16 acc[2][NT];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < TAPS; ++i) {
-#pragma unroll
-      for (int j = 0; j < TAPS; ++j) {
-        const int pid0 = (2 * wid + i) * PW + rx + j;
-        const int pid1 = pid0 + PW;
-        const half8_t fa0 = *reinterpret_cast<const half8_t*>(pt + pid0 * CB + ((kg ^ ((pid0 >> 3) & 1)) << 4));
-        const half8_t fa1 = *reinterpret_cast<const half8_t*>(pt + pid1 * CB + ((kg ^ ((pid1 >> 3) & 1)) << 4));
-        const char* bb = Wl + (lane & 31) * WPITCH + (i * TAPS + j) * 32 + kg * 16;
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn) {
-          const half8_t fb = *reinterpret_cast<const half8_t*>(bb + tn * 32 * WPITCH);
-          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb, acc[0][tn], 0, 0, 0);
-          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb, acc[1][tn], 0, 0, 0);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // next patch landed; every wave is done with this patch AND with the previous tile's staging reads
-    buf ^= 1;
+    pool_mfma<TAPS, 0, KSTEPS / 2>(pt, Wl, wid, lane, acc);
+    if (late && ptile >= 0) pool_out(ptile, buf ^ 1, v);
+    pool_mfma<TAPS, KSTEPS / 2, KSTEPS>(pt, Wl, wid, lane, acc);
 
     int img, pty, ptx;
     tile_origin(tile, img, pty, ptx);
     const int cy0 = 2 * PTH * pty - 1, cx0 = 2 * PTW * ptx - 1;  // conv-output coordinates of tile row/col 0
+    // BN + ReLU on packed registers; h0 = the wave's first row, v = max of its two rows.  Per (tn, q): channels
+    // tn*32 + 8q + 4kg + (0..3) of column rx.
+    half4_t h0[NT][4];
+    const half4_t z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    f32x4 scv[NT][4], shv[NT][4];  // BN constants of this lane's 2 x 16 channels: all reads issued before the first use
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int ry = 2 * wid + tm;
-      const bool rowok = (unsigned)(cy0 + ry) < (unsigned)p.OH;
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        scv[tn][q] = *reinterpret_cast<const f32x4*>(bnc + tn * 32 + 8 * q + 4 * kg);
+        shv[tn][q] = *reinterpret_cast<const f32x4*>(bnc + NCH + tn * 32 + 8 * q + 4 * kg);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc4 = scv[tn][q], sh4 = shv[tn][q];
+        const f32x4 a0 = {acc[0][tn][4 * q], acc[0][tn][4 * q + 1], acc[0][tn][4 * q + 2], acc[0][tn][4 * q + 3]};
+        const f32x4 a1 = {acc[1][tn][4 * q], acc[1][tn][4 * q + 1], acc[1][tn][4 * q + 2], acc[1][tn][4 * q + 3]};
+        h0[tn][q] = __builtin_elementwise_max(__builtin_convertvector(__builtin_elementwise_fma(a0, sc4, sh4), half4_t), z);
+        v[tn][q] = __builtin_elementwise_max(__builtin_convertvector(__builtin_elementwise_fma(a1, sc4, sh4), half4_t), z);
+      }
+    // conv positions outside the image count as 0: only tiles on the image border have any (wave-uniform test)
+    if (cy0 < 0 || cx0 < 0 || cy0 + CTH > p.OH || cx0 + CTW > p.OW) {
+      const bool colok = (unsigned)(cx0 + rx) < (unsigned)p.OW;
+      const bool ok0 = colok && (unsigned)(cy0 + 2 * wid) < (unsigned)p.OH;
+      const bool ok1 = colok && (unsigned)(cy0 + 2 * wid + 1) < (unsigned)p.OH;
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int px = (r & 3) + 8 * (r >> 2) + 4 * kg;
-          float v = fmaxf(acc[tm][tn][r] * sc[tn] + sh[tn], 0.f);
-          if (!(rowok && (unsigned)(cx0 + px) < (unsigned)p.OW)) v = 0.f;
-          *reinterpret_cast<half_t*>(stg + (ry * CTW + px) * SPX + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
+        for (int q = 0; q < 4; ++q) {
+          h0[tn][q] = ok0 ? h0[tn][q] : z;
+          v[tn][q] = ok1 ? v[tn][q] : z;
         }
     }
-    __syncthreads();
-    // pooled tile: PTH x PTW pixels x 8 chunks of 8 channels; pooled (ppy, ppx) <- conv tile rows 2ppy..2ppy+2, cols 2ppx..2ppx+2
-    for (int e = tid; e < PTH * PTW * 8; e += 512) {
-      const int c8 = e & 7, pp = e >> 3;
-      const int ppy = pp / PTW, ppx = pp - ppy * PTW;
-      const int oy = pty * PTH + ppy, ox = ptx * PTW + ppx;
-      if (oy >= POH || ox >= POW) continue;
-      half8_t m = *reinterpret_cast<const half8_t*>(stg + ((2 * ppy) * CTW + 2 * ppx) * SPX + c8 * 16);
+    if (wid > 0) {  // this wave's first row, for the wave above
+      char* xw = xbuf + (buf * 7 + (wid - 1)) * XROW + rx * XPITCH + 8 * kg;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+      for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          if (dy == 0 && dx == 0) continue;
-          const half8_t t = *reinterpret_cast<const half8_t*>(stg + ((2 * ppy + dy) * CTW + 2 * ppx + dx) * SPX + c8 * 16);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) m[k] = t[k] > m[k] ? t[k] : m[k];
-        }
-      *reinterpret_cast<half8_t*>(y + ((long long)(img * POH + oy) * POW + ox) * p.ldo + p.y_coff + c8 * 8) = m;
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<half4_t*>(xw + tn * 64 + q * 16) = h0[tn][q];
     }
-    // the barrier after the next tile's MFMA phase orders these staging reads before the next staging writes
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[tn][q] = __builtin_elementwise_max(v[tn][q], h0[tn][q]);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // next patch landed, every wave is done with this one; the exchanged rows are visible
+    ptile = tile;
+    buf ^= 1;
   }
+  if (ptile >= 0) pool_out(ptile, buf ^ 1, v);
 }
 
 template <int TAPS>
@@ -456,7 +598,8 @@ int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
   constexpr int PATCH_SLOT = ((PH * PW * CB + 1023) / 1024) * 1024;
   constexpr int WPITCH = TAPS * TAPS * 32 + 16;
   constexpr int W_BYTES = ((64 * WPITCH + 1023) / 1024) * 1024;
-  constexpr int LDS = W_BYTES + 2 * PATCH_SLOT + CTH * CTW * 128;
+  constexpr int LDS = W_BYTES + 2 * PATCH_SLOT + 2 * 7 * XROW + 7 * OROW + 512;
+  static_assert(LDS <= 160 * 1024, "LDS");
   S2dParams p = p0;
   const int pty = am_cdiv(POH, PTH), ptx = am_cdiv(POW, PTW);
   p.ntiles = p.B * pty * ptx;
@@ -496,7 +639,10 @@ int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* 
   for (int t = 0; t < g->ntaps; ++t)
     if (g->dy[t] != g->dy[0] + t || g->dx[t] != g->dy[0]) return AM_ERR_UNSUPPORTED;
   if ((long long)g->B * g->OH * g->OW < 64 * 1024) return AM_ERR_UNSUPPORTED;  // small problems: gather-GEMM
+  const long long x_bytes = (long long)g->B * g->IH * g->IW * CB;
+  if (x_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;  // 32-bit buffer offsets (B = 291 at 720p)
   S2dParams p;
+  p.x_bytes = (unsigned)x_bytes;
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats;
   p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.OH = g->OH; p.OW = g->OW; p.ldo = g->ldo; p.y_coff = g->y_coff;
   p.off0 = g->dy[0]; p.relu = relu; p.N = g->N;
