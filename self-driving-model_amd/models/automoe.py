@@ -53,6 +53,8 @@ class AutoMoE(nn.Module):
         # kernel (identical features, no 70 MB/img logits round trip); `expert_outputs` then holds their LOW-RES
         # [B,C,h,w] logits instead of the upsampled ones.  Default False = the reference's dict contents exactly.
         self.fuse_expert_pooling = False
+        self.overlap_policy_backbone = os.environ.get("AUTOMOE_OVERLAP_BACKBONE", "1") != "0"
+        self._side_stream = None
         self.to(device)
 
     def _create_experts(self) -> nn.ModuleList:
@@ -123,12 +125,14 @@ class AutoMoE(nn.Module):
                                         device=batch["image"].device))
         return outs
 
-    def _run_experts_fused(self, batch, nhwc):
-        outs, feats = [], []
+    def _run_experts_fused(self, batch, nhwc, fork=None):
+        """Experts (trunk + head + fused upsample/pool), then their extractor MLPs.  `fork` (a callable) runs between the
+        two: the launch-latency-bound MLP tail that starts here can then overlap whatever `fork` put on another stream."""
+        outs, feats, pend = [], [], []
         for i, (expert, extractor) in enumerate(zip(self.experts, self.expert_extractors.extractors)):
             if hasattr(expert, "pooled_logits"):
                 pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
-                feats.append(extractor.feature_extractor(pooled, start=2))  # skip pool + flatten
+                pend.append((extractor, pooled, True))
                 outs.append(low.detach()[..., : expert.num_classes].permute(0, 3, 1, 2))
             else:
                 if self.expert_configs[i]["type"] == "nuscenes":
@@ -136,20 +140,46 @@ class AutoMoE(nn.Module):
                 else:
                     out = expert(batch["image"], nhwc_input=nhwc)
                 outs.append(out)
-                feats.append(extractor(out))
+                pend.append((extractor, out, False))
+        if fork is not None:
+            fork()
+        for extractor, t, pooled in pend:
+            feats.append(extractor.feature_extractor(t, start=2) if pooled else extractor(t))  # pooled: skip pool + flatten
         return outs, feats
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         runtime.begin_step(batch["image"].device)
         context_features = self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
+        # The policy backbone (a conv stack on the image) does not depend on the experts; the extractor / gating MLPs
+        # that follow them are dozens of launch-latency-bound kernels on [B, <=512] tensors.  With overlap_policy_backbone
+        # the backbone runs on a side stream forked AFTER the experts (so the big kernels do not fight each other) and
+        # joined before the policy heads: the MLP tail hides under its convolutions, in forward and -- autograd replays
+        # each node on its forward stream -- in backward.
+        side = {}
+
+        def fork_backbone():
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=batch["image"].device)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                side["feat"] = self.policy_head.backbone(batch["image"], nhwc_input=nhwc)
+
+        overlap = self.overlap_policy_backbone and self.fuse_expert_pooling and batch["image"].is_cuda
         if self.fuse_expert_pooling:
-            expert_outputs, expert_features = self._run_experts_fused(batch, nhwc)
+            expert_outputs, expert_features = self._run_experts_fused(batch, nhwc, fork_backbone if overlap else None)
         else:
             expert_outputs = self._run_experts(batch, nhwc)
             expert_features = self.expert_extractors.extract_features(expert_outputs)
         gating_output = self.gating_network(expert_features, context_features)
-        policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc)
+        if "feat" in side:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            side["feat"].record_stream(torch.cuda.current_stream())
+            policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc,
+                                             backbone_feat=side["feat"])
+        else:
+            policy_output = self.policy_head(batch["image"], context=gating_output["combined_output"], nhwc_input=nhwc)
         hconv.flush_bn_counters()
         speed_seq = policy_output.get("speed")
         speed_out = speed_seq[:, -1:].contiguous() if speed_seq is not None and speed_seq.dim() == 2 else None

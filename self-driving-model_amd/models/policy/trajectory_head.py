@@ -48,8 +48,9 @@ class TrajectoryPolicy(nn.Module):
                                       Linear(hidden, horizon))
 
     def forward(self, image: torch.Tensor, context: Optional[torch.Tensor] = None,
-                nhwc_input: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        feat = self.backbone(image, nhwc_input=nhwc_input)
+                nhwc_input: Optional[torch.Tensor] = None, backbone_feat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        # backbone_feat: the backbone's output when the caller already ran it (AutoMoE overlaps it with the gating MLPs)
+        feat = backbone_feat if backbone_feat is not None else self.backbone(image, nhwc_input=nhwc_input)
         x = torch.cat([feat, context], dim=1) if context is not None else feat
         wp = self.head_wp(x).view(-1, self.horizon, 2)
         spd = self.head_spd(x).view(-1, self.horizon)

@@ -61,12 +61,15 @@ class GradBucketReducer:
     def reset(self):
         self._pending = [n for (_, _, n) in self.buckets]
         self._handles = []
+        self._streams = [set() for _ in self.buckets]  # streams whose backward nodes wrote into each bucket
 
     def _make_hook(self, idx):
         def hook(_param):
             if self.paused:
                 return
             b = self._bucket_of[idx]
+            if self.flat.is_cuda:
+                self._streams[b].add(torch.cuda.current_stream())
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
@@ -75,6 +78,13 @@ class GradBucketReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         sl = self.flat[lo:hi]
+        if self.flat.is_cuda:
+            # autograd runs every node on its forward stream (AutoMoE puts the policy backbone on a side stream): the
+            # launching stream first waits for every stream that accumulated into this bucket
+            cur = torch.cuda.current_stream()
+            for st in self._streams[b]:
+                if st != cur:
+                    cur.wait_stream(st)
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
