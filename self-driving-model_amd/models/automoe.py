@@ -55,6 +55,8 @@ class AutoMoE(nn.Module):
         self.fuse_expert_pooling = False
         self.overlap_policy_backbone = os.environ.get("AUTOMOE_OVERLAP_BACKBONE", "1") != "0"
         self._side_stream = None
+        self._expert_streams = []
+        self.parallel_experts = os.environ.get("AUTOMOE_PARALLEL_EXPERTS", "1") != "0"
         self.to(device)
 
     def _create_experts(self) -> nn.ModuleList:
@@ -128,10 +130,25 @@ class AutoMoE(nn.Module):
     def _run_experts_fused(self, batch, nhwc, fork=None):
         """Experts (trunk + head + fused upsample/pool), then their extractor MLPs.  `fork` (a callable) runs between the
         two: the launch-latency-bound MLP tail that starts here can then overlap whatever `fork` put on another stream."""
+        # Frozen experts in train-mode BatchNorm are chains of conv -> 5-us statistics finalize -> normalise passes: every
+        # finalize drains the chip.  The experts are independent, so each runs on its own stream and the bubbles of one
+        # are filled by the others' kernels.
         outs, feats, pend = [], [], []
+        par = self.parallel_experts and batch["image"].is_cuda
+        main = torch.cuda.current_stream() if par else None
+        forked = main.record_event() if par else None  # experts 1.. start here, beside expert 0 (not behind it)
         for i, (expert, extractor) in enumerate(zip(self.experts, self.expert_extractors.extractors)):
             if hasattr(expert, "pooled_logits"):
-                pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
+                if par and i > 0:
+                    while len(self._expert_streams) < i:
+                        self._expert_streams.append(torch.cuda.Stream(device=batch["image"].device))
+                    st = self._expert_streams[i - 1]
+                    st.wait_event(forked)
+                    with torch.cuda.stream(st):
+                        pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
+                    pooled.record_stream(main); low.record_stream(main)
+                else:
+                    pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
                 pend.append((extractor, pooled, True))
                 outs.append(low.detach()[..., : expert.num_classes].permute(0, 3, 1, 2))
             else:
@@ -141,6 +158,9 @@ class AutoMoE(nn.Module):
                     out = expert(batch["image"], nhwc_input=nhwc)
                 outs.append(out)
                 pend.append((extractor, out, False))
+        if par:
+            for st in self._expert_streams:
+                main.wait_stream(st)
         if fork is not None:
             fork()
         for extractor, t, pooled in pend:
