@@ -151,19 +151,38 @@ def main():
         "config": {"workload": "BASELINE configs[3] variant 4a: full AutoMoE (det+seg+drv ResNet-18 experts frozen, gating, "
                                "policy) train step, 3x720x1280", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "loss_scale": runtime.loss_scale(), "optimizer": "AdamW(4e-4,1e-4)+clip1.0",
-                   "hipgraph": step._graph is not None, "fused_expert_pooling": bool(model.fuse_expert_pooling)},
+                   "hipgraph": step._graph is not None, "fused_expert_pooling": bool(model.fuse_expert_pooling),
+                   "expert_streams": bool(model.parallel_experts), "policy_backbone_stream": bool(model.overlap_policy_backbone)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- roofline of the dominant kernel (and of the whole conv forward family): per-launch HIP events on the launch stream ----
         saved = (step._graph, step.use_graph)  # per-launch events need eager launches, not a graph replay
         step._graph, step.use_graph = None, False
+        # ... and one kernel on the chip at a time: in the timed step the experts and the policy backbone run on their own
+        # streams, where an event pair around a launch would also count the kernels it shares the chip with
+        saved_par = (model.parallel_experts, model.overlap_policy_backbone)
+        model.parallel_experts = model.overlap_policy_backbone = False
         hconv.TIMER = hconv.KernelTimer()
         for _ in range(2):
             run()
         summ = hconv.TIMER.summary()
         per_kernel = hconv.TIMER.summary(by="kernel")
         hconv.TIMER = None
+        model.parallel_experts, model.overlap_policy_backbone = saved_par
+        # the clock the chip held inside the dominant kernel (s_memtime vs the 100 MHz s_memrealtime, workgroup 0 of the last
+        # 256x256 ring launch): the 2.5 PFLOP/s spec peak is quoted at 2.4 GHz
+        import ctypes
+        clk = (ctypes.c_longlong * 3)()
+        in_kernel = None
+        try:
+            hconv._L().am_diag_ring_clock(clk, hconv.stream())
+            if clk[1] > 0 and clk[2] > 0:
+                ghz = clk[0] / (clk[1] * 10.0)  # cycles per ns
+                in_kernel = {"clock_ghz": round(ghz, 3), "cycles_per_kstep": round(clk[0] / clk[2], 1), "mfma_floor_cycles_per_kstep": 1024,
+                             "peak_at_clock_tflops": round(PEAK_F16_TFLOPS * ghz / 2.4, 1)}
+        except Exception as e:  # noqa: BLE001
+            in_kernel = {"error": repr(e)[:120]}
         step._graph, step.use_graph = saved
         # dominant kernel = the one with the largest share of the step (what the rocprof summary under profiles/ ranks first)
         dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
@@ -172,7 +191,7 @@ def main():
         fam_ach = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
-                           "kernel": dom_name, "launches_per_step": dom["launches"] // 2,
+                           "kernel": dom_name, "in_kernel": in_kernel, "launches_per_step": dom["launches"] // 2,
                            "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                            "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                            "ms_per_step": round(dom["ms"] / 2, 3),

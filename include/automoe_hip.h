@@ -101,6 +101,12 @@ int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const fl
  * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k. */
 int am_conv_last_variant(void);
 
+/* Diagnostic (bench.py roofline leg): what workgroup 0 of the last conv_ring_k<256,256> launch measured inside its K-loop --
+ * out[0] shader-clock cycles (s_memtime), out[1] ticks of the constant 100 MHz clock (s_memrealtime), out[2] K-steps (the
+ * MFMA floor is 1024 cycles per K-step).  out[0] / out[1] * 100 MHz = the clock the chip held under that kernel.
+ * Synchronises `stream`. */
+int am_diag_ring_clock(long long* out, am_stream_t stream);
+
 /* Weight gradient of the same gather-GEMM (torch conv2d backward w.r.t. weight):
  *   dw[n, t*krun + r] += scale * sum_m dy[m, n] * gather(m, t, r),  fp32, atomically accumulated,
  * dw row-major [>=N rows][ntaps*krun] (caller zeroes it, e.g. zero_grad).  `dy` is read at the

@@ -12,6 +12,10 @@
 
 namespace amr {
 
+// Diagnostic: shader-clock cycles and 100 MHz wall-clock ticks that workgroup 0 of the last 256x256 launch spent in its
+// K-loop, and its K-step count (am_diag_ring_clock; bench.py reports the clock the chip held under this kernel).
+__device__ long long g_ring_clk[3];
+
 constexpr int RING_MAX_TAPS = 9;
 constexpr unsigned OOB = 0x80000000u;  // offsets at or above every buffer's num_records
 
@@ -36,10 +40,10 @@ __device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes
                                            (lds_ptr)dst, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTG = 3, int ILV = 0>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) {
   constexpr int BKB = 64;                  // K-step in bytes (32 halves = two k16 MFMA sub-steps)
-  constexpr int NW = WM * WN, NTH = NW * 64;
+  constexpr int NW = WM * WN, NTH = NW * 64, NSTG = 3;
   typedef half_t T;
   constexpr int RPI = 1024 / BKB;          // rows per wave-instruction (16)
   constexpr int AI = BM / RPI / NW;        // A instructions per wave per K-step
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   // tile `kk` = (tap, kin): A rows gather [tap offset + kin*64 B) of each pixel's run, B rows K bytes [kk*64, +64)
   auto issue_tile = [&](int kk, int tap, int kin, int stage) {
     const int toff = __builtin_amdgcn_readlane(tapv, tap);
-    const unsigned uoff = ILV == 2 ? 0u : (unsigned)(toff + kin * BKB);  // ILV == 2: timing probe, every K-step re-reads the same lines
+    const unsigned uoff = (unsigned)(toff + kin * BKB);
     char* As = smem + stage * STAGE + wid * (AI * 1024);
     char* Bs = smem + stage * STAGE + BM * BKB + wid * (BI * 1024);
 #pragma unroll
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j)
-      buffer_to_lds16(p.w, p.w_bytes, Bs + j * 1024, b_off[j], ILV == 2 ? 0 : kk * BKB);
+      buffer_to_lds16(p.w, p.w_bytes, Bs + j * 1024, b_off[j], kk * BKB);
   };
 
   // issue cursor (tile index, tap, K-step inside the tap), advanced without divisions.  Tiles past the last one are
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     ikin = wrap ? 0 : ikin + 1;
     itap = wrap ? itap + 1 : itap;
   };
-#pragma unroll
-  for (int st = 0; st < NSTG - 1; ++st) { issue_tile(ikk, itap, ikin, st); advance(); }
+  issue_tile(ikk, itap, ikin, 0); advance();
+  issue_tile(ikk, itap, ikin, 1); advance();
 
   // fragment read addressing: lane reads row (lane&31) of its 32-row sub-tile, 16-byte chunk (2*ks + lane>>5) ^ swz(row);
   // swz(row) is the same for the TM (TN) sub-tiles of a lane because they are 32 rows apart
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   //   middle: tile kk+1 has landed (at most tile kk+2's loads outstanding) -> barrier -> read its sub-step 0
   //   bottom: 8 MFMAs of sub-step 1
   half8_t a0[TM], b0[TN], a1[TM], b1[TN];
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLOAD) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -158,55 +162,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
 #pragma unroll
   for (int t = 0; t < TN; ++t) b0[t] = *reinterpret_cast<const half8_t*>(smem + fb[0] + t * 32 * BKB);
 
+  const bool diag = BN >= 256 && blockIdx.x == 0 && tid == 0;
+  const long long c0 = diag ? clock64() : 0, w0 = diag ? wall_clock64() : 0;
   int stage = 0;
   for (int kk = 0; kk < nk; ++kk) {
     const char* S = smem + stage * STAGE;
     const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
-    if (ILV != 6) {
 #pragma unroll
     for (int t = 0; t < TM; ++t) a1[t] = *reinterpret_cast<const half8_t*>(S + fa[1] + t * 32 * BKB);
 #pragma unroll
     for (int t = 0; t < TN; ++t) b1[t] = *reinterpret_cast<const half8_t*>(S + fb[1] + t * 32 * BKB);
-    } else {
-#pragma unroll
-    for (int t = 0; t < TM; ++t) asm volatile("" : "+v"(a1[t]));
-#pragma unroll
-    for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(b1[t]));
-    }
-    if (ILV != 5) issue_tile(ikk, itap, ikin, stage == 0 ? NSTG - 1 : stage - 1);
+    issue_tile(ikk, itap, ikin, stage == 0 ? 2 : stage - 1);
     advance();
-    if (ILV != 1) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
-    if (ILV == 1) {  // fragment reads first, then one DMA issue per MFMA gap: the partner wave's MFMAs cover the issue stalls
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-      for (int j = 0; j < NLOAD; ++j) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - NLOAD, 0);
-    }
     __builtin_amdgcn_sched_barrier(0);
     // own part of tile kk+1 landed, own reads of tile kk returned (so the next iteration may overwrite ... tile kk-1's
     // stage is the one written above; tile kk's stage is written after the NEXT barrier)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTG - 2) * NLOAD) : "memory");
-    if (ILV != 7) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOAD) : "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char* Sn = smem + nstage * STAGE;
-    if (ILV != 6) {
 #pragma unroll
     for (int t = 0; t < TM; ++t) a0[t] = *reinterpret_cast<const half8_t*>(Sn + fa[0] + t * 32 * BKB);
 #pragma unroll
     for (int t = 0; t < TN; ++t) b0[t] = *reinterpret_cast<const half8_t*>(Sn + fb[0] + t * 32 * BKB);
-    } else {
-#pragma unroll
-    for (int t = 0; t < TM; ++t) asm volatile("" : "+v"(a0[t]));
-#pragma unroll
-    for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(b0[t]));
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -215,8 +198,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     __builtin_amdgcn_sched_barrier(0);
     stage = nstage;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the NSTG-1 tiles issued past the end
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles issued past the end
   __syncthreads();  // all fragment reads done before the epilogue reuses the stage buffers
+  if (diag) {
+    g_ring_clk[0] = clock64() - c0;
+    g_ring_clk[1] = wall_clock64() - w0;
+    g_ring_clk[2] = nk;
+  }
 
   // ---- epilogue: BN statistics from the accumulators, bias, ReLU, LDS-staged 16-byte stores ----
   for (int r = tid; r < BM; r += NTH) {  // output pixel of every tile row
@@ -318,7 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTG = 3, int ILV = 0>
+template <int BM, int BN, int WM, int WN>
 int launch_ring(const RingParams& p0, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * 64;
   RingParams p = p0;
@@ -326,15 +314,15 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
   p.ntiles = am_cdiv(p.g.N, BN);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr size_t EPI = 8192 + (size_t)WM * WN * (TM * 32) * (TN * 64 + 16);
-  const size_t lds = NSTG * STAGE > EPI ? NSTG * STAGE : EPI;
+  const size_t lds = 3 * STAGE > EPI ? 3 * STAGE : EPI;
   static bool attr_done = false;
   if (lds > 64 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ring_k<BM, BN, WM, WN, NSTG, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ring_k<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   g_am_conv_variant = BN >= 256 ? AM_CV_RING_256x256 : AM_CV_RING_256x128;
-  hipLaunchKernelGGL((conv_ring_k<BM, BN, WM, WN, NSTG, ILV>), dim3(p.mtiles * p.ntiles), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_ring_k<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(WM * WN * 64), lds, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -365,27 +353,17 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   for (int t = 0; t < RING_MAX_TAPS; ++t)
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
   const long long mt256 = (p.M + 255) / 256;
-  static int var = -1;
-  if (var < 0) { const char* e = getenv("AM_RING_VAR"); var = e ? atoi(e) : 0; }
-  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) {
-    switch (var) {
-      case 1: return launch_ring<256, 256, 2, 4, 4, 0>(p, s);
-      case 2: return launch_ring<256, 256, 2, 4, 3, 1>(p, s);
-      case 3: return launch_ring<256, 256, 2, 4, 4, 1>(p, s);
-      case 4: return launch_ring<256, 256, 2, 4, 3, 2>(p, s);
-      case 5: return launch_ring<256, 256, 2, 4, 3, 5>(p, s);
-      case 6: return launch_ring<256, 256, 2, 4, 3, 6>(p, s);
-      case 7: return launch_ring<256, 256, 2, 4, 3, 7>(p, s);
-      default: return launch_ring<256, 256, 2, 4>(p, s);
-    }
-  }
-  if (mt256 * ((g->N + 127) / 128) >= 256) {
-    switch (var) {
-      case 1: return launch_ring<256, 128, 4, 2, 4, 0>(p, s);
-      case 2: return launch_ring<256, 128, 4, 2, 3, 1>(p, s);
-      case 3: return launch_ring<256, 128, 4, 2, 4, 1>(p, s);
-      default: return launch_ring<256, 128, 4, 2>(p, s);
-    }
-  }
+  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) return launch_ring<256, 256, 2, 4>(p, s);
+  static int n128 = -1;
+  if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
+  if (mt256 * ((g->N + 127) / 128) >= 256) return n128 == 1 ? launch_ring<256, 128, 2, 2>(p, s) : launch_ring<256, 128, 4, 2>(p, s);
   return AM_ERR_UNSUPPORTED;
+}
+
+// out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = K-steps of workgroup 0's K-loop in the last 256x256 ring launch
+// (synchronises the stream).  MFMA floor of that loop: 1024 cycles per K-step.
+extern "C" int am_diag_ring_clock(long long* out, void* stream) {
+  if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return AM_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(amr::g_ring_clk), 3 * sizeof(long long)) != hipSuccess) return AM_ERR_LAUNCH;
+  return AM_OK;
 }
