@@ -58,6 +58,13 @@ int am_version(void);
  * Packed weights `w`: row-major [am_conv_npad(N)][ntaps*krun] of `dtype`, zero padded rows.
  * krun*sizeof(dtype) must be a multiple of 64.  pix_shift: log2(elements per input pixel) when a
  * run spans several pixels (first-layer trick: 8 pixels x 8 channels), 31 when it covers one.
+ * osplit (0 = off; needs N == 2*osplit, f16, a shape the LDS-DMA ring kernels cover, else AM_ERR_UNSUPPORTED): output
+ * columns [0, osplit) of row m are stored at its output pixel, columns [osplit, N) at that pixel + osplit_stride elements.
+ * This is how the input gradient of a 3x3 / stride-2 / pad-1 convolution runs as ONE gather-GEMM instead of four parity-
+ * class launches: a row is the 2x2 block of dX pixels (2my.., 2mx..), its N = 4*Cin columns are ordered (py, px, ci), the
+ * four taps are the 2x2 neighbourhood of dY pixels it depends on (weights zero where a class does not use a tap); with
+ * osplit = 2*Cin and osplit_stride = one image row the block leaves as two contiguous 2*Cin-element segments (full
+ * cache lines) instead of four strided Cin-element ones.
  * `stats` (optional, may be NULL): [AM_STATS_REPLICAS][2][N] fp64, zeroed by the caller;
  * receives per-channel sum and sum of squares of the pre-bias accumulator (BatchNorm batch
  * statistics, torch.nn.BatchNorm2d in train mode) -- bias-free so the variance is shift-free.
@@ -72,6 +79,7 @@ typedef struct am_conv_geom {
   int32_t N;
   int16_t dy[AM_MAX_TAPS];
   int16_t dx[AM_MAX_TAPS];
+  int32_t osplit, osplit_stride; /* 0, or: columns [osplit, N) of an output row land osplit_stride elements after its pixel */
 } am_conv_geom;
 
 int am_conv_npad(int N);

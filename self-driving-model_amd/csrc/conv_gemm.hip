@@ -366,6 +366,7 @@ int check_geom(const am_conv_geom* g, int dtype) {
   if ((g->ldi * es) % 16 != 0 || (g->x_coff * es) % 16 != 0) return AM_ERR_ARG;
   if (g->pix_shift < 0 || g->pix_shift > 31) return AM_ERR_ARG;
   if ((long long)g->B * g->MH * g->MW > 0x7fffffffLL || (long long)g->B * g->OH * g->OW > 0x7fffffffLL) return AM_ERR_ARG;
+  if (g->osplit < 0 || (g->osplit > 0 && (g->N != 2 * g->osplit || g->osplit % 8 != 0 || g->osplit_stride % 8 != 0))) return AM_ERR_ARG;
   return AM_OK;
 }
 
@@ -576,6 +577,9 @@ int g_am_conv_variant = AM_CV_NONE;
 
 extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
 
+int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+                     hipStream_t s);  // conv_ring.hip
+
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;
   if (N > 32) return 64;
@@ -601,6 +605,8 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   for (int t = 0; t < AM_MAX_TAPS; ++t)
     p.tap_off[t] = t < g->ntaps ? ((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g->osplit > 0)  // split output rows (fused stride-2 dgrad): ring kernels only
+    return dtype == AM_F16 && bias == nullptr && !relu && stats == nullptr ? am_conv_ring_f16(g, x, w, bias, relu, y, stats, s) : AM_ERR_UNSUPPORTED;
   if (dtype == AM_F16 && !use_v1_only()) {
     // 3-channel first layers on the space-to-depth image: weights-stationary patch kernel
     rc = am_conv_s2d_f16(g, 0, x, w, bias, nullptr, nullptr, relu, y, stats, s);

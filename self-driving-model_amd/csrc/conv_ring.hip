@@ -300,8 +300,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
       const int row = q / CPRW, cc = q - row * CPRW;
       const int op = opix_s[wm * TM * 32 + row];
       const int col0 = n0 + wn * TN * 32 + cc * 8;
+      // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
+      const size_t seg = (g.osplit > 0 && col0 >= g.osplit) ? (size_t)(g.osplit_stride - g.osplit) : 0;
       if (op >= 0 && col0 < ncols)
-        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
+        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0 + seg) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
     }
   }
 }

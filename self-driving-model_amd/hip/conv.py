@@ -190,6 +190,44 @@ def dgrad_plans(s: ConvSpec, B: int, IH: int, IW: int, ld_dx: int, ld_dy: int, e
     return plans
 
 
+FUSE_S2_DGRAD = os.environ.get("AM_FUSE_S2_DGRAD", "1") != "0"  # tests flip this to compare the one-launch stride-2 input gradient with the four parity-class launches
+
+# kernel row/column index a dX pixel of parity p takes from the dY pixel at offset d (3x3, stride 2, pad 1): iy = 2*oy - 1 + kh
+_S2_TAP = {(0, 0): 1, (1, 0): 2, (1, 1): 0}  # (parity, dY offset) -> kh; parity 0 never reads offset 1
+
+
+def dgrad_s2_plan(s: ConvSpec, B: int, IH: int, IW: int, ld_dx: int, ld_dy: int, es: int):
+    """Input gradient of a 3x3 / stride-2 / pad-1 convolution as ONE gather-GEMM (include/automoe_hip.h, `osplit`): row =
+    the 2x2 block of dX pixels (2y.., 2x..), columns (py, px, ci), taps = the 2x2 dY neighbourhood (y+dy, x+dx).  None when
+    the layer / tensor layout is not covered (the caller then runs the parity-class plans)."""
+    if not (s.k == 3 and s.stride == 2 and s.pad == 1 and not s.first and es == 2):
+        return None
+    if IH % 2 or IW % 2 or ld_dx != s.cin or (2 * s.cin) % 8 or (ld_dy * es) % 64:
+        return None
+    OH, OW = out_size(IH, s), out_size(IW, s)
+    return _geom(B=B, MH=IH // 2, MW=IW // 2, IH=OH, IW=OW, ldi=ld_dy, x_coff=0, OH=IH, OW=IW, ldo=ld_dx, y_coff=0,
+                 oys=2, oy0=0, oxs=2, ox0=0, iys=1, ixs=1, ntaps=4, krun=ld_dy, pix_shift=31, N=4 * s.cin,
+                 dy=[0, 0, 1, 1], dx=[0, 1, 0, 1], osplit=2 * s.cin, osplit_stride=IW * ld_dx)
+
+
+def pack_dgrad_s2(w: torch.Tensor, dtype: torch.dtype, ld_dy: int) -> torch.Tensor:
+    """OIHW -> [npad(4*I)][4*ld_dy]: row (py, px, ci), column (dy, dx, co); zero where the class does not use the tap."""
+    O, I = w.shape[0], w.shape[1]
+    npad = _L().am_conv_npad(4 * I)
+    out = torch.zeros(npad, 4 * ld_dy, dtype=dtype, device=w.device)
+    wt = w.detach().permute(1, 2, 3, 0)  # [I, kh, kw, O]
+    for py in range(2):
+        for px in range(2):
+            for dy in range(2):
+                for dx in range(2):
+                    kh, kw = _S2_TAP.get((py, dy)), _S2_TAP.get((px, dx))
+                    if kh is None or kw is None:
+                        continue
+                    r0, c0 = (py * 2 + px) * I, (dy * 2 + dx) * ld_dy
+                    out[r0:r0 + I, c0:c0 + O] = wt[:, kh, kw, :].to(dtype)
+    return out
+
+
 def pack_dgrad(w: torch.Tensor, taps, dtype: torch.dtype, ld_dy: int) -> Optional[torch.Tensor]:
     """OIHW -> [npad(I)][len(taps)*ld_dy] for one parity class (O zero-padded to the dY pixel stride)."""
     if not taps:
@@ -259,6 +297,9 @@ class PackedWeights:
 
     def get_fwd(self, w: torch.Tensor, s: ConvSpec, dtype: torch.dtype) -> torch.Tensor:
         return self._layout("fwd", w, dtype, lambda p: pack_fwd(p, s, torch.float32))
+
+    def get_dgrad_s2(self, w: torch.Tensor, dtype: torch.dtype, ld_dy: int) -> torch.Tensor:
+        return self._layout(("dgrad_s2", ld_dy), w, dtype, lambda p: pack_dgrad_s2(p, torch.float32, ld_dy))
 
     def get_dgrad(self, w: torch.Tensor, s: ConvSpec, dtype: torch.dtype, idx: int, taps, ld_dy: int) -> Optional[torch.Tensor]:
         return self._layout(("dgrad", idx, tuple(taps), ld_dy), w, dtype, lambda p: pack_dgrad(p, taps, torch.float32, ld_dy))
@@ -492,9 +533,18 @@ class ConvBnAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, IH, IW, ldi = x.shape
             dx = torch.empty_like(x)
-            for idx, (gd, taps) in enumerate(dgrad_plans(s, B, IH, IW, ldi, ldo, es)):
-                wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
-                conv_gemm(gd, dz, wd, None, False, dx, None, k_real=len(taps) * s.cout, kind="conv_dgrad")
+            g2 = dgrad_s2_plan(s, B, IH, IW, ldi, ldo, es) if FUSE_S2_DGRAD else None
+            if g2 is not None:
+                try:
+                    conv_gemm(g2, dz, cfg.cache.get_dgrad_s2(w, dtype, ldo), None, False, dx, None, k_real=2.25 * s.cout, kind="conv_dgrad")
+                except RuntimeError as e:
+                    if "UNSUPPORTED" not in str(e):
+                        raise
+                    g2 = None
+            if g2 is None:
+                for idx, (gd, taps) in enumerate(dgrad_plans(s, B, IH, IW, ldi, ldo, es)):
+                    wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
+                    conv_gemm(gd, dz, wd, None, False, dx, None, k_real=len(taps) * s.cout, kind="conv_dgrad")
         if ctx.needs_input_grad[1]:
             ktot = g.ntaps * g.krun
             dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)

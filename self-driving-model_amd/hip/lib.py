@@ -30,7 +30,8 @@ class ConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "MH", "MW", "IH", "IW", "ldi", "x_coff", "OH", "OW", "ldo", "y_coff", "oys", "oy0", "oxs", "ox0",
         "iys", "ixs", "ntaps", "krun", "pix_shift", "N")] + [("dy", ctypes.c_int16 * AM_MAX_TAPS),
-                                                               ("dx", ctypes.c_int16 * AM_MAX_TAPS)]
+                                                               ("dx", ctypes.c_int16 * AM_MAX_TAPS),
+                                                               ("osplit", ctypes.c_int32), ("osplit_stride", ctypes.c_int32)]
 
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,

@@ -556,3 +556,40 @@ def test_first_layer_weight_gradient_kernels_vs_torch(spec):
         dw = hc.unpack_wgrad(a, s, torch.float16)
     ref = torch.nn.grad.conv2d_weight(img.half().float(), w.shape, dz[..., :cout].float().permute(0, 3, 1, 2).contiguous(), stride=2, padding=pad)
     assert rel_err(dw, ref) < 2e-3, rel_err(dw, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(32, 64, 2, 256, 256), (64, 128, 2, 320, 320), (128, 256, 4, 240, 256)])
+def test_fused_stride2_dgrad_vs_parity_class_launches_and_torch(case):
+    """3x3 / stride-2 / pad-1 input gradient (EasyBackbone convs 2-4, trajectory_head.py:15-22; ResNet stage entries): the
+    one-launch form (2x2 dX block per GEMM row, `osplit` output rows) must agree with the four parity-class launches to the
+    last bit of their common arithmetic (same products, fp32 accumulation in a different order) and with torch."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    xr, wr = x.clone().requires_grad_(), w.clone()
+    yr = F.conv2d(xr.half().float(), wr.half().float(), None, stride=2, padding=1)
+    probe = (torch.randn(yr.shape, generator=g)).half().float()
+    (yr * probe).sum().backward()
+    spec = hc.ConvSpec(cin, cout, 3, 2, 1)
+    grads = {}
+    for fused in (True, False):
+        hc.FUSE_S2_DGRAD = fused
+        try:
+            with runtime.precision(torch.float16, 1.0):
+                xd = nhwc(x, torch.float16).requires_grad_()
+                wd = w.to(_dev())
+                cfg = hc._Cfg(spec, hc.PackedWeights(), None, False, 1.0)
+                if fused:  # the covered shapes must really take the one-launch path
+                    assert hc.dgrad_s2_plan(spec, B, H, W, cin, cout, 2) is not None
+                y = hc.conv_bn_act(xd, wd, None, None, False, None, cfg, False)
+                (y[..., :cout].float() * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+            grads[fused] = xd.grad.float().cpu()
+        finally:
+            hc.FUSE_S2_DGRAD = True
+    assert rel_err(grads[True], grads[False]) < 2e-3
+    close(grads[True], grads[False], rtol=2e-2, atol=2e-2, what="fused vs parity-class dgrad")
+    assert rel_err(grads[True].permute(0, 3, 1, 2)[:, :cin], xr.grad) < 3e-3
