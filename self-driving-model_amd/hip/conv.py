@@ -321,7 +321,10 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for kind, flops, e0, e1, kernel in self.records:
-            d = out.setdefault(kind if by == "kind" else kernel, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            # input-gradient launches of a forward kernel are listed apart: the one-launch stride-2 form executes 16/9 of its
+            # algorithmic FLOPs (structural zeros in the 2x2-block weight matrix), a forward launch exactly its own
+            name = kernel + " [dgrad]" if kind == "conv_dgrad" else kernel
+            d = out.setdefault(kind if by == "kind" else name, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += e0.elapsed_time(e1)
