@@ -139,7 +139,9 @@ def main():
     def run():
         # once the step is captured the synthetic batch lives in the graph's input buffers (what a loader's H2D copy would
         # target): no per-step device-to-device copy of the 354 MB image batch
-        step(step.input_buffers or batch)
+        # ... and with frozen experts the NEXT step's expert forward (its own graph on its own stream, same synthetic data in its
+        # own input buffer) is launched behind this step's forward, so it shares the chip with this step's backward / optimizer
+        step(step.input_buffers or batch, next_batch=step.expert_input_buffers)
 
     dt = timed_steps(run, args.steps, args.warmup, distributed)
     value = world * args.batch * args.steps / dt
@@ -152,7 +154,7 @@ def main():
                                "policy) train step, 3x720x1280", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "loss_scale": runtime.loss_scale(), "optimizer": "AdamW(4e-4,1e-4)+clip1.0",
                    "hipgraph": step._graph is not None, "fused_expert_pooling": bool(model.fuse_expert_pooling),
-                   "expert_streams": bool(model.parallel_experts), "policy_backbone_stream": bool(model.overlap_policy_backbone)},
+                   "expert_prefetch": step._graph_experts is not None, "expert_streams": bool(model.parallel_experts), "policy_backbone_stream": bool(model.overlap_policy_backbone)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -10,7 +10,7 @@ MI355X-first differences in HOW (results are the reference's):
 """
 import os
 import warnings
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
@@ -127,17 +127,16 @@ class AutoMoE(nn.Module):
                                         device=batch["image"].device))
         return outs
 
-    def _run_experts_fused(self, batch, nhwc, fork=None):
-        """Experts (trunk + head + fused upsample/pool), then their extractor MLPs.  `fork` (a callable) runs between the
-        two: the launch-latency-bound MLP tail that starts here can then overlap whatever `fork` put on another stream."""
+    def _run_expert_trunks(self, batch, nhwc):
+        """The experts themselves (trunk + head + fused upsample/pool): [(tensor for the extractor, pooled?)], outputs."""
         # Frozen experts in train-mode BatchNorm are chains of conv -> 5-us statistics finalize -> normalise passes: every
         # finalize drains the chip.  The experts are independent, so each runs on its own stream and the bubbles of one
         # are filled by the others' kernels.
-        outs, feats, pend = [], [], []
+        outs, pend = [], []
         par = self.parallel_experts and batch["image"].is_cuda
         main = torch.cuda.current_stream() if par else None
         forked = main.record_event() if par else None  # experts 1.. start here, beside expert 0 (not behind it)
-        for i, (expert, extractor) in enumerate(zip(self.experts, self.expert_extractors.extractors)):
+        for i, expert in enumerate(self.experts):
             if hasattr(expert, "pooled_logits"):
                 if par and i > 0:
                     while len(self._expert_streams) < i:
@@ -149,7 +148,7 @@ class AutoMoE(nn.Module):
                     pooled.record_stream(main); low.record_stream(main)
                 else:
                     pooled, low = expert.pooled_logits(batch["image"], nhwc_input=nhwc)
-                pend.append((extractor, pooled, True))
+                pend.append((pooled, True))
                 outs.append(low.detach()[..., : expert.num_classes].permute(0, 3, 1, 2))
             else:
                 if self.expert_configs[i]["type"] == "nuscenes":
@@ -157,17 +156,44 @@ class AutoMoE(nn.Module):
                 else:
                     out = expert(batch["image"], nhwc_input=nhwc)
                 outs.append(out)
-                pend.append((extractor, out, False))
+                pend.append((out, False))
         if par:
             for st in self._expert_streams:
                 main.wait_stream(st)
+        return pend, outs
+
+    def _run_experts_fused(self, batch, nhwc, fork=None, expert_cache=None):
+        """Experts, then their extractor MLPs.  `fork` (a callable) runs between the two: the launch-latency-bound MLP tail
+        that starts here can then overlap whatever `fork` put on another stream.  `expert_cache`: the experts' results when
+        they were computed ahead of this step (forward_experts)."""
+        if expert_cache is not None:
+            pend, outs = expert_cache["pend"], expert_cache["outs"]
+        else:
+            pend, outs = self._run_expert_trunks(batch, nhwc)
         if fork is not None:
             fork()
-        for extractor, t, pooled in pend:
+        feats = []
+        for extractor, (t, pooled) in zip(self.expert_extractors.extractors, pend):
             feats.append(extractor.feature_extractor(t, start=2) if pooled else extractor(t))  # pooled: skip pool + flatten
         return outs, feats
 
-    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def experts_frozen(self) -> bool:
+        return not any(p.requires_grad for e in self.experts for p in e.parameters())
+
+    @torch.no_grad()
+    def forward_experts(self, batch: Dict[str, torch.Tensor]) -> Dict:
+        """The frozen-expert phase of forward() on its own (own statistics arena, nothing of the trainable part): a trainer
+        may run it for the NEXT batch while the rest of the current step (policy, gating, backward, optimizer) is still on
+        the GPU -- frozen experts do not depend on the update.  Pass the result to forward(batch, expert_cache=...)."""
+        if not (self.fuse_expert_pooling and self.experts_frozen()):
+            raise RuntimeError("forward_experts: needs frozen experts and fuse_expert_pooling")
+        runtime.begin_step(batch["image"].device, phase="experts")
+        nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())
+        pend, outs = self._run_expert_trunks(batch, nhwc)
+        hconv.flush_bn_counters()
+        return {"pend": pend, "outs": outs}
+
+    def forward(self, batch: Dict[str, torch.Tensor], expert_cache: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
         runtime.begin_step(batch["image"].device)
         context_features = self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
@@ -188,7 +214,7 @@ class AutoMoE(nn.Module):
 
         overlap = self.overlap_policy_backbone and self.fuse_expert_pooling and batch["image"].is_cuda
         if self.fuse_expert_pooling:
-            expert_outputs, expert_features = self._run_experts_fused(batch, nhwc, fork_backbone if overlap else None)
+            expert_outputs, expert_features = self._run_experts_fused(batch, nhwc, fork_backbone if overlap else None, expert_cache)
         else:
             expert_outputs = self._run_experts(batch, nhwc)
             expert_features = self.expert_extractors.extract_features(expert_outputs)

@@ -93,7 +93,11 @@ def precision(dtype: torch.dtype, loss_scale: float | None = None):
 # Every conv+BN layer needs a small zeroed fp64 accumulator (forward sums, backward sums).  Allocating and zero-filling
 # ~130 of them per step costs more launches than the arithmetic; instead one buffer is zeroed by a single memset at
 # begin_step() and handed out in slices.  A slice is only valid until the next begin_step().
-_ARENA = {"buf": None, "off": 0, "cap": 1 << 22}
+# Two arenas: "main" for a whole model step, "experts" for the frozen-expert phase when a trainer runs it as its own graph
+# one step ahead of the rest (training/train_gating_network.py): the two phases of neighbouring steps then overlap on the
+# GPU and must not share accumulators.
+_ARENAS = {"main": {"buf": None, "off": 0, "cap": 1 << 22}, "experts": {"buf": None, "off": 0, "cap": 1 << 22}}
+_PHASE = {"name": "main"}
 
 
 _STEP = {"counter": None}
@@ -107,11 +111,12 @@ def step_counter(device) -> torch.Tensor:
     return _STEP["counter"]
 
 
-def begin_step(device=None):
-    """Zero the statistics arena (one memset) and bump the device step counter.  Called at the start of every model
-    forward / train step."""
-    a = _ARENA
-    if device is not None:
+def begin_step(device=None, phase: str = "main"):
+    """Zero the phase's statistics arena (one memset), make it the current one and (phase "main") bump the device step
+    counter.  Called at the start of every model forward / train step."""
+    a = _ARENAS[phase]
+    _PHASE["name"] = phase
+    if device is not None and phase == "main":
         step_counter(device).add_(1)
     if a["buf"] is None or (device is not None and a["buf"].device != torch.device(device)):
         a["buf"] = torch.zeros(a["cap"], dtype=torch.float64, device=device if device is not None else "cuda")
@@ -121,7 +126,7 @@ def begin_step(device=None):
 
 
 def arena_zeros(n: int, device) -> torch.Tensor:
-    a = _ARENA
+    a = _ARENAS[_PHASE["name"]]
     if a["buf"] is None or a["buf"].device != torch.device(device) or a["off"] + n > a["cap"]:
         return torch.zeros(n, dtype=torch.float64, device=device)  # outside a step (or exhausted): plain allocation
     out = a["buf"][a["off"]:a["off"] + n]

@@ -112,14 +112,25 @@ class GatingTrainStep:
         self._static_batch = None
         self._static_losses = None
         self._eager_steps = 0
+        # Expert prefetch (frozen experts only): the experts' forward is its own hipGraph on its own stream and runs for the
+        # NEXT batch while the rest of this step -- gating / policy forward, backward, all-reduce, optimizer: kernels that
+        # are HBM-, atomics- or latency-bound -- is still on the GPU beside the experts' MFMA-bound convolutions.  Frozen
+        # experts do not depend on the update, so the training trajectory is unchanged.
+        self.prefetch_experts = os.environ.get("AUTOMOE_PREFETCH_EXPERTS", "1") != "0"
+        self._graph_experts = None      # graph A: forward_experts(static expert batch)
+        self._expert_stream = None
+        self._expert_batch = None       # graph A's static input ({"image": ...})
+        self._cache_a = self._cache_b = None  # expert results: as graph A writes them / the copy graph B reads
+        self._ev_experts = self._ev_copied = None
+        self._experts_pending = False   # graph A already launched for the batch of the next call
 
-    def _fwd_bwd(self, batch):
+    def _fwd_bwd(self, batch, expert_cache=None):
         self.optimizer.zero_grad()
         # parameter gradients go straight into the flat buffer unless the bucketed all-reduce is listening to autograd's
         # accumulate hooks (eager multi-rank mode)
         runtime.set_direct_grads(not self.reducer.enabled or self.reducer.paused)
         try:
-            pred = self.model(batch)
+            pred = self.model(batch) if expert_cache is None else self.model(batch, expert_cache=expert_cache)
             losses = fused_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
             losses["total_loss"].backward()
         finally:
@@ -130,11 +141,37 @@ class GatingTrainStep:
         self._static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
         self.reducer.paused = True  # hooks must not launch collectives inside the capture
         try:
-            g = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread touches the runtime concurrently: only police this thread
             mode = "thread_local" if self.reducer.enabled else "global"
+            cache_b = None
+            if (self.prefetch_experts and hasattr(self.core, "forward_experts") and self.core.fuse_expert_pooling
+                    and self.core.experts_frozen() and batch["image"].is_cuda):
+                self._expert_stream = torch.cuda.Stream(device=batch["image"].device)
+                self._expert_batch = {"image": self._static_batch["image"].clone()}
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode=mode):
+                    cache_a = self.core.forward_experts(self._expert_batch)
+                # graph B reads its own copy of the experts' results (tensors or dicts of tensors), taken right before its replay
+                flat_a, flat_b = [], []
+
+                def mirror(v):
+                    if isinstance(v, torch.Tensor):
+                        flat_a.append(v)
+                        flat_b.append(torch.empty_like(v))
+                        return flat_b[-1]
+                    if isinstance(v, dict):
+                        return {k: mirror(x) for k, x in v.items()}
+                    if isinstance(v, (list, tuple)):
+                        return type(v)(mirror(x) for x in v)
+                    return v
+
+                cache_b = {"pend": [(mirror(t), pooled) for t, pooled in cache_a["pend"]], "outs": [mirror(o) for o in cache_a["outs"]]}
+                self._cache_a, self._cache_b = flat_a, flat_b
+                self._ev_experts, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
+                self._graph_experts = ga
+            g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=mode):
-                losses = self._fwd_bwd(self._static_batch)
+                losses = self._fwd_bwd(self._static_batch, cache_b)
             self._graph, self._static_losses = g, losses
         except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
             import traceback
@@ -142,7 +179,7 @@ class GatingTrainStep:
             warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing without a graph\n"
                           + "".join(traceback.format_exc().splitlines(True)[-14:]))
             self.use_graph = False
-            self._graph = None
+            self._graph = self._graph_experts = None
             torch.cuda.synchronize()
         finally:
             if self.reducer.enabled:
@@ -150,7 +187,7 @@ class GatingTrainStep:
                 ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
-                    self._graph, self.use_graph = None, False
+                    self._graph, self._graph_experts, self.use_graph = None, None, False
             self.reducer.paused = self._graph is not None
 
     @property
@@ -159,15 +196,46 @@ class GatingTrainStep:
         copies straight into them (or passes them back to ``__call__``) saves the per-step device-to-device copy."""
         return self._static_batch if self._graph is not None else None
 
-    def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def _launch_experts(self, batch):
+        """Graph A for `batch` on the expert stream (after the previous step's copy of its results has been taken)."""
+        st = self._expert_stream
+        st.wait_event(self._ev_copied)  # (never recorded yet: no-op)
+        with torch.cuda.stream(st):
+            img = batch["image"]
+            if img.data_ptr() != self._expert_batch["image"].data_ptr():
+                self._expert_batch["image"].copy_(img, non_blocking=True)
+            self._graph_experts.replay()
+            self._ev_experts.record(st)
+
+    @property
+    def expert_input_buffers(self):
+        """Graph A's static input ({"image": ...}) when the expert prefetch is active (else None): where a loader puts the
+        NEXT batch's image, to be passed as ``next_batch`` without a device-to-device copy."""
+        return self._expert_batch if self._graph_experts is not None and self._graph is not None else None
+
+    def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """One step on `batch`.  `next_batch` (optional): the batch of the NEXT call; with frozen experts and a captured
+        step its expert forward is launched now and overlaps this step's backward / optimizer (the next call must then be
+        made with exactly that batch)."""
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:
             self._capture(batch)
         if self._graph is not None:
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
                     self._static_batch[k].copy_(v, non_blocking=True)
+            if self._graph_experts is not None:
+                if not self._experts_pending:
+                    self._launch_experts(batch)
+                main = torch.cuda.current_stream()
+                main.wait_event(self._ev_experts)
+                torch._foreach_copy_(self._cache_b, self._cache_a)  # graph A may now overwrite its results
+                self._ev_copied.record(main)
+                self._experts_pending = False
             self._graph.replay()
             losses = self._static_losses
+            if self._graph_experts is not None and next_batch is not None:
+                self._launch_experts(next_batch)
+                self._experts_pending = True
             self.reducer.reduce_all()
         else:
             losses = self._fwd_bwd(batch)
@@ -182,9 +250,15 @@ def train_one_epoch(model, loader, optimizer, device, epoch_idx, epochs, rank, c
     step = step or GatingTrainStep(model, config)
     total = torch.zeros((), device=device)
     n = 0
-    for batch in loader:
-        batch = {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
-        losses = step(batch)
+    to_dev = lambda b: {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in b.items()}  # noqa: E731
+    it = iter(loader)
+    nxt = next(it, None)
+    nxt = to_dev(nxt) if nxt is not None else None
+    while nxt is not None:
+        batch = nxt
+        nxt = next(it, None)
+        nxt = to_dev(nxt) if nxt is not None else None
+        losses = step(batch, next_batch=nxt)  # one batch of lookahead: the frozen experts run on it during this step's backward
         total += losses["total_loss"].detach()
         n += 1
     return float(total.item()) / max(1, n)

@@ -478,6 +478,45 @@ def test_train_step_hipgraph_matches_eager():
             assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked advanced identically
 
 
+def test_expert_prefetch_follows_the_serial_trajectory():
+    """Frozen experts as their own hipGraph, launched one batch ahead (`next_batch`): on a stream of DIFFERENT batches the
+    losses, the trained parameters and the experts' BatchNorm buffers must follow the step that runs everything in one graph
+    (a stale or overwritten expert result would show on the alternating batches)."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+    from oracle import torch_ref as oref
+    ref = seed_module_(oref.create_automoe_model(AUTOMOE_CFG, "cpu"), 190)
+    batches = [{k: v.to(_dev()) for k, v in _batch(2, 64, 96, 191 + i).items()} for i in range(3)]
+    seq = [batches[i % 3] for i in range(8)]
+    finals = {}
+    with runtime.precision(torch.float32):
+        for prefetch in (False, True):
+            m = create_automoe_model(AUTOMOE_CFG, "cpu")
+            m.load_state_dict(ref.state_dict())
+            m.to(_dev())
+            m.freeze_experts()
+            m.train()
+            for d in m.modules():
+                if isinstance(d, torch.nn.Dropout):
+                    d.p = 0.0
+            step = GatingTrainStep(m, {"learning_rate": 1e-3, "weight_decay": 1e-4}, use_graph=True)
+            step.prefetch_experts = prefetch
+            losses = []
+            for i, b in enumerate(seq):
+                nxt = seq[i + 1] if (prefetch and i + 1 < len(seq)) else None
+                losses.append(float(step(b, next_batch=nxt)["total_loss"]))
+            assert step._graph is not None and (step._graph_experts is not None) == prefetch
+            finals[prefetch] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    np.testing.assert_allclose(finals[True][0], finals[False][0], rtol=2e-3, atol=1e-4)
+    assert len(set(round(v, 4) for v in finals[False][0][:3])) == 3  # the batches really differ
+    for k, v in finals[False][1].items():
+        if v.dtype.is_floating_point:
+            close(finals[True][1][k], v, rtol=5e-3, atol=5e-4, what=k)
+        else:
+            assert torch.equal(finals[True][1][k], v), k
+
+
 def test_frozen_stem_fused_pool_matches_unfused():
     """Frozen trunk, train-mode BN, fp16: the two-pass fused stem (statistics pass; conv+BN+ReLU+maxpool pass) must give
     the trunk the same features and the same running statistics as conv -> BN -> ReLU -> MaxPool run separately."""

@@ -34,7 +34,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert set(L.protos) == declared
     assert L.am_version() >= 1
     assert [L.am_conv_npad(n) for n in (3, 14, 32, 33, 64, 65, 128, 192, 512)] == [32, 32, 32, 64, 64, 128, 128, 256, 512]
-    assert ctypes.sizeof(lib.ConvGeom) == 21 * 4 + 2 * 2 * lib.AM_MAX_TAPS  # matches struct am_conv_geom
+    assert ctypes.sizeof(lib.ConvGeom) == 21 * 4 + 2 * 2 * lib.AM_MAX_TAPS + 2 * 4  # matches struct am_conv_geom (+ osplit, osplit_stride)
 
 
 def test_abi_rejects_bad_arguments_without_a_gpu(lib):
