@@ -141,7 +141,7 @@ def main():
         # target): no per-step device-to-device copy of the 354 MB image batch
         # ... and with frozen experts the NEXT step's expert forward (its own graph on its own stream, same synthetic data in its
         # own input buffer) is launched behind this step's forward, so it shares the chip with this step's backward / optimizer
-        step(step.input_buffers or batch, next_batch=step.expert_input_buffers)
+        step(step.input_buffers or batch, next_batch=True)
 
     dt = timed_steps(run, args.steps, args.warmup, distributed)
     value = world * args.batch * args.steps / dt

@@ -169,6 +169,17 @@ class GatingTrainStep:
                 self._cache_a, self._cache_b = flat_a, flat_b
                 self._ev_experts, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
                 self._graph_experts = ga
+                # one-time costs (a graph's first launch on a new stream, the copy kernels' module load: ~10 ms each) are paid
+                # here, not in the caller's first step.  The experts' BatchNorm buffers (all graph A changes) are put back.
+                bufs = [b for e in self.core.experts for b in e.buffers()]
+                saved = [b.clone() for b in bufs]
+                torch.cuda.synchronize()
+                with torch.cuda.stream(self._expert_stream):
+                    ga.replay()
+                torch._foreach_copy_(flat_b, flat_a)
+                torch.cuda.synchronize()
+                for b, v in zip(bufs, saved):
+                    b.copy_(v)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=mode):
                 losses = self._fwd_bwd(self._static_batch, cache_b)
@@ -201,9 +212,10 @@ class GatingTrainStep:
         st = self._expert_stream
         st.wait_event(self._ev_copied)  # (never recorded yet: no-op)
         with torch.cuda.stream(st):
-            img = batch["image"]
-            if img.data_ptr() != self._expert_batch["image"].data_ptr():
-                self._expert_batch["image"].copy_(img, non_blocking=True)
+            if batch is not True:  # True: the caller's loader already wrote the batch into expert_input_buffers
+                img = batch["image"]
+                if img.data_ptr() != self._expert_batch["image"].data_ptr():
+                    self._expert_batch["image"].copy_(img, non_blocking=True)
             self._graph_experts.replay()
             self._ev_experts.record(st)
 
@@ -214,9 +226,10 @@ class GatingTrainStep:
         return self._expert_batch if self._graph_experts is not None and self._graph is not None else None
 
     def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """One step on `batch`.  `next_batch` (optional): the batch of the NEXT call; with frozen experts and a captured
-        step its expert forward is launched now and overlaps this step's backward / optimizer (the next call must then be
-        made with exactly that batch)."""
+        """One step on `batch`.  `next_batch` (optional): the batch of the NEXT call -- a dict with its "image", or True when
+        the caller's loader writes the next image straight into ``expert_input_buffers`` (before this step is captured: the
+        first batch, which the buffer is initialised with).  With frozen experts and a captured step its expert forward is
+        launched now and overlaps this step's backward / optimizer; the next call must then be made with exactly that batch."""
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:
             self._capture(batch)
         if self._graph is not None:
