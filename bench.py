@@ -210,7 +210,7 @@ def main():
         others = {}
         try:
             others["cfg2_drivable_expert_train_B16_img_s"] = bench_drivable(16, 6, 4)
-            others["cfg3_detection_expert_hungarian_train_B8_img_s"] = bench_detection(8, 6, 4)
+            others["cfg3_detection_expert_hungarian_train_B8_img_s"] = bench_detection(8, 12, 4)
             others.update(bench_matcher())
             others.update(bench_inference(model, 64, 20, 3))
             model.unfreeze_experts()
