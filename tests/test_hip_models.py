@@ -927,3 +927,54 @@ def test_frozen_strided_block_fused_shortcut_bn_matches_unfused(dtype):
     assert rel_err(outs[True][0], outs[False][0]) < (2e-3 if dtype == torch.float16 else 1e-5)
     for k, v in outs[False][1].items():
         close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
+
+
+def test_full_size_automoe_properties_b32_720p():
+    """BASELINE configs[3] at its full size (per-GPU batch 32, 3x720x1280, fp16), where the oracle is too slow to compare
+    against: size-independent properties.  (1) the reference's own gating invariants (tests/test_gating_network.py:76-80,
+    212-213: weights >= 0, rows sum to 1) and output shapes; (2) eval-mode results are per-image: the batch of 32 and its
+    two halves give the same rows (to fp16 rounding: tile choice follows the row count); (3) a frozen-expert train step
+    (hipGraph + expert prefetch, as benchmarked) leaves every expert parameter untouched bit for bit, moves the trainable
+    ones, advances the experts' BatchNorm buffers by exactly one update per step, and its loss falls over six steps on a
+    fixed batch."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+    dev = _dev()
+    B, H, W = 32, 720, 1280
+    with runtime.precision(torch.float16):
+        torch.manual_seed(5)
+        m = create_automoe_model(AUTOMOE_CFG, dev)
+        batch = synthetic.carla_sequence_batch(B, H, W, 10, dev, seed=3)
+        m.eval()
+        with torch.no_grad():
+            full = m(batch)
+            halves = [m({k: v[i * 16:(i + 1) * 16] for k, v in batch.items()}) for i in range(2)]
+        assert full["waypoints"].shape == (B, 10, 2) and full["speed_seq"].shape == (B, 10) and full["speed"].shape == (B, 1)
+        w = full["expert_weights"].float()
+        assert w.shape == (B, 3) and bool((w >= 0).all())
+        close(w.sum(dim=1), torch.ones(B), rtol=0, atol=1e-6, what="gating weights sum to 1")
+        for k in ("waypoints", "speed_seq", "expert_weights", "gate_logits", "combined_features"):
+            assert torch.isfinite(full[k]).all(), k
+            # not bit for bit: the dispatcher picks tiles (and with them the fp32 summation order) by the row count
+            assert rel_err(full[k].float(), torch.cat([h[k] for h in halves]).float()) < 5e-3, f"{k}: batch of 32 vs two batches of 16"
+        # frozen-expert train step as benchmarked
+        m.freeze_experts()
+        m.train()
+        expert_w = {k: v.detach().clone() for k, v in m.experts.state_dict().items() if v.dtype.is_floating_point and "running" not in k}
+        tracked0 = {k: int(v) for k, v in m.experts.state_dict().items() if k.endswith("num_batches_tracked")}
+        trainable0 = {k: p.detach().clone() for k, p in m.named_parameters() if p.requires_grad}
+        step = GatingTrainStep(m, {"learning_rate": 4e-4, "weight_decay": 1e-4})
+        losses = []
+        for i in range(6):
+            losses.append(float(step(step.input_buffers or batch, next_batch=(True if i < 5 else None))["total_loss"]))
+        assert step._graph is not None and step._graph_experts is not None
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        sd = m.experts.state_dict()
+        for k, v in expert_w.items():
+            assert torch.equal(sd[k], v), f"frozen expert parameter {k} changed"
+        for k, n0 in tracked0.items():
+            assert int(sd[k]) == n0 + 6, (k, n0, int(sd[k]))  # six expert forwards: the prefetches replace, not add
+        moved = [k for k, p in m.named_parameters() if p.requires_grad and not torch.equal(p.detach(), trainable0[k])]
+        assert len(moved) == len(trainable0), set(trainable0) - set(moved)
