@@ -10,8 +10,14 @@ fp32 parameter gradients are unscaled.  1.0 in fp32 mode.
 from __future__ import annotations
 
 import contextlib
+import os
 
-import torch
+# A train step keeps up to six HIP streams busy (main, policy backbone, expert graph + two expert forks, collectives); the
+# runtime maps streams onto 4 hardware queues by default and streams that share one serialise.  Read when HIP initialises,
+# i.e. at the first device call after this import; a value the user exported wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 _STATE = {"dtype": torch.float16, "loss_scale": 16384.0, "weight_epoch": 0}
 
