@@ -315,7 +315,8 @@ def bench_inference(model, B, runs, warmup):
     for i in range(warmup + runs):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model(batch)
+        with torch.no_grad():  # SURVEY 8(d) config 5 / run_automoe.py:34-53 model_infer
+            model(batch)
         torch.cuda.synchronize()
         if i >= warmup:
             lat.append((time.perf_counter() - t0) * 1e3)

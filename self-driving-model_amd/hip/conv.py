@@ -190,6 +190,7 @@ def dgrad_plans(s: ConvSpec, B: int, IH: int, IW: int, ld_dx: int, ld_dy: int, e
     return plans
 
 
+FOLD_EVAL_BN = os.environ.get("AM_FOLD_EVAL_BN", "1") != "0"  # eval-mode BatchNorm folded into the conv weights / bias (f16 inference)
 FUSE_S2_DGRAD = os.environ.get("AM_FUSE_S2_DGRAD", "1") != "0"  # tests flip this to compare the one-launch stride-2 input gradient with the four parity-class launches
 
 # kernel row/column index a dX pixel of parity p takes from the dY pixel at offset d (3x3, stride 2, pad 1): iy = 2*oy - 1 + kh
@@ -259,6 +260,7 @@ class PackedWeights:
         self.total = 0
         self.flat = None
         self.fresh = False
+        self.fold = None    # (key, folded fp32 weight, folded bias, its PackedWeights): eval-mode BatchNorm folded into the conv
 
     def _probe_map(self, w: torch.Tensor, builder):
         probe = torch.arange(1, w.numel() + 1, dtype=torch.float32).reshape(w.shape)  # exact in fp32 below 2^24 elements
@@ -379,6 +381,7 @@ class _Cfg:
     def __init__(self, spec: ConvSpec, cache: PackedWeights, bn=None, relu=False, loss_scale=1.0, orig_hw=None):
         self.spec, self.cache, self.bn, self.relu, self.loss_scale = spec, cache, bn, relu, loss_scale
         self.orig_hw = orig_hw  # original image size when the input is the space-to-depth image (first layers)
+        self.no_grad = False    # set per call by conv_bn_act(): nothing will ask this call for a gradient
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -410,6 +413,21 @@ class ConvBnAct(torch.autograd.Function):
             y, mean, rstd = raw, None, None
         else:
             use_batch = training or bn.running_mean is None
+            if not use_batch and residual is None and dtype == torch.float16 and FOLD_EVAL_BN and cfg.no_grad:
+                # Inference (eval-mode BatchNorm, nothing wants a gradient): y = act(conv(x, w) * scale + shift) with constant
+                # scale / shift is the same convolution with weights w * scale[n] and bias shift[n] -- no normalise pass, no
+                # raw tensor.  The folded master weight is rebuilt only when a parameter or running statistic changed.
+                key = (w._version, w.data_ptr(), gamma._version, beta._version, bn.running_mean._version, bn.running_var._version,
+                       -1 if b is None else b._version, float(bn.eps))
+                if cfg.cache.fold is None or cfg.cache.fold[0] != key:
+                    sc = gamma.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                    sh = beta.detach().float() - bn.running_mean.float() * sc
+                    if b is not None:
+                        sh = sh + b.detach().float() * sc
+                    cfg.cache.fold = (key, (w.detach().float() * sc.view(-1, 1, 1, 1)).contiguous(), sh.contiguous(), PackedWeights())
+                _, wf, bf, cache_f = cfg.cache.fold
+                conv_gemm(g, x, cache_f.get_fwd(wf, s, dtype), bf, cfg.relu, raw, None, k_real=s.cin * s.k * s.k)
+                return raw
             stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev) if use_batch else None
             # Frozen first layer in train-mode BN (AutoMoE's gating stage): two light passes over the image instead of
             # conv -> raw output -> normalise pass.  Only when nothing here needs a gradient (raw output is not kept).
@@ -561,6 +579,8 @@ def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
         cfg.orig_hw = getattr(x, "orig_hw", None)
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
+    # (inside Function.forward grad mode is always off and needs_input_grad still mirrors requires_grad: decide here)
+    cfg.no_grad = not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in (x, w, b, gamma, beta, residual))
     return ConvBnAct.apply(x, w, b, gamma, beta, residual, cfg, training)
 
 

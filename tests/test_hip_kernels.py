@@ -593,3 +593,46 @@ def test_fused_stride2_dgrad_vs_parity_class_launches_and_torch(case):
     assert rel_err(grads[True], grads[False]) < 2e-3
     close(grads[True], grads[False], rtol=2e-2, atol=2e-2, what="fused vs parity-class dgrad")
     assert rel_err(grads[True].permute(0, 3, 1, 2)[:, :cin], xr.grad) < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, 1, True), (128, 256, 3, 2, 1, False), (3, 64, 7, 2, 3, True), (64, 128, 1, 2, 0, False)])
+def test_eval_bn_folding_matches_normalise_pass_and_torch(case):
+    """Inference (torch.no_grad, eval-mode BatchNorm, f16): the BatchNorm folded into the conv weights / bias epilogue must
+    agree with the conv -> normalise-pass sequence and with torch (conv2d -> batch_norm(eval) -> relu), conv bias included."""
+    import torch.nn as nn
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    cin, cout, k, st, pad, relu = case
+    B, H, W = 2, 66, 94
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(cout, generator=g)); bn.bias.copy_(0.2 * torch.randn(cout, generator=g))
+        bn.running_mean.copy_(0.3 * torch.randn(cout, generator=g)); bn.running_var.copy_(0.5 + torch.rand(cout, generator=g))
+    bn.eval()
+    with torch.no_grad():
+        yr = F.batch_norm(F.conv2d(x.half().float(), w.half().float(), b, stride=st, padding=pad), bn.running_mean, bn.running_var,
+                          bn.weight, bn.bias, False, 0.0, bn.eps)
+        yr = F.relu(yr) if relu else yr
+    spec = hc.ConvSpec(cin, cout, k, st, pad, first=(cin == 3))
+    bnd = nn.BatchNorm2d(cout); bnd.load_state_dict(bn.state_dict()); bnd.to(_dev()).eval()
+    outs = {}
+    for fold in (True, False):
+        hc.FOLD_EVAL_BN = fold
+        try:
+            with runtime.precision(torch.float16, 1.0), torch.no_grad():
+                xd = hops.image_to_nhwc(x.to(_dev()), torch.float16) if cin == 3 else nhwc(x, torch.float16)
+                pk = hc.PackedWeights()
+                cfg = hc._Cfg(spec, pk, bnd, relu, 1.0)
+                y = hc.conv_bn_act(xd, w.to(_dev()), b.to(_dev()), bnd, relu, None, cfg, False)
+                assert (pk.fold is not None) == fold
+            outs[fold] = nchw(y, cout)
+        finally:
+            hc.FOLD_EVAL_BN = True
+    assert rel_err(outs[True], outs[False]) < 2e-3
+    assert rel_err(outs[True], yr) < 3e-3 and rel_err(outs[False], yr) < 3e-3
