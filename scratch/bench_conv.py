@@ -14,6 +14,8 @@ layers = [  # name, spec, IH, IW
     ("l2 3x3 128->128", hc.ConvSpec(128, 128, 3, 1, 1), 90, 160),
     ("l2.0 ds 1x1 64->128 s2", hc.ConvSpec(64, 128, 1, 2, 0), 180, 320),
     ("l3.0 3x3 128->256 s2", hc.ConvSpec(128, 256, 3, 2, 1), 90, 160),
+    ("l3.0 ds 1x1 128->256 s2", hc.ConvSpec(128, 256, 1, 2, 0), 90, 160),
+    ("l4.0 ds 1x1 256->512 s2", hc.ConvSpec(256, 512, 1, 2, 0), 45, 80),
     ("l3 3x3 256->256", hc.ConvSpec(256, 256, 3, 1, 1), 45, 80),
     ("l4.0 3x3 256->512 s2", hc.ConvSpec(256, 512, 3, 2, 1), 45, 80),
     ("l4 3x3 512->512", hc.ConvSpec(512, 512, 3, 1, 1), 23, 40),
