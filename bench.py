@@ -242,23 +242,16 @@ def main():
 
 
 def bench_drivable(B, steps, warmup):
-    """BASELINE configs[1]: drivable-area expert train step, batch 16, 3x720x1280, fp16."""
-    from self_driving_model_amd.hip import ops as hops
+    """BASELINE configs[1]: drivable-area expert train step (training/train_bdd100k_ddp.py trainer), batch 16, 3x720x1280, fp16."""
     from self_driving_model_amd.models.experts import BDDDrivableExpert
     from self_driving_model_amd.training import synthetic
-    from self_driving_model_amd.training.optim import FusedAdamW
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
     dev = torch.device("cuda", torch.cuda.current_device())
     m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
-    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
     b = synthetic.bdd_drivable_batch(B, H, W, 3, dev, seed=0)
-
-    def run():
-        opt.zero_grad()
-        loss = hops.CrossEntropy2d.apply(m(b["image"]), b["mask"], 255)
-        loss.backward()
-        opt.step()
-
-    dt = timed_steps(run, steps, warmup, False)
+    loader = synthetic.SyntheticLoader(b, steps)
+    tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 2e-4, "weight_decay": 1e-5, "epochs": 1, "run_name": "bench"})
+    dt = timed_steps(lambda: tr.train_step(b), steps, warmup, False)
     return round(B * steps / dt, 2)
 
 

@@ -554,6 +554,7 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 }  // namespace
 
+int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s);  // conv_wgrad_ring.hip
 int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
                           const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
@@ -656,6 +657,8 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
       rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
+    rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, s);  // LDS-DMA ring kernel (conv_wgrad_ring.hip): N % 128 == 0, long contractions
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
     if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s);
     return launch_wgrad<half_t, 64, 4>(p, s);
   }

@@ -85,6 +85,13 @@ class BDDTrainer:
             self.matcher = HungarianMatcher(cost_class=config.get("cost_class", 1.0), cost_bbox=config.get("cost_bbox", 5.0),
                                             cost_giou=config.get("cost_giou", 2.0))
         self.best_val_loss = float("inf")
+        # zero_grad + forward + loss (matcher included: cost, assignment and scatter all stay on the device) + backward are
+        # ~1000 launches for 9-11 ms of GPU work at the reference's batch sizes: captured into one hipGraph after two eager
+        # steps, as in GatingTrainStep.  Batches whose tensor shapes differ from the captured ones (a ragged last batch, a
+        # different GT padding) run eagerly.
+        self.use_graph = os.environ.get("AUTOMOE_HIPGRAPH", "1") != "0" if config.get("use_graph") is None else bool(config["use_graph"])
+        self._graph = self._static = self._static_loss = None
+        self._eager_steps = 0
 
     def load_training_state(self, checkpoint):
         if checkpoint.get("optimizer_state_dict") is not None:
@@ -103,11 +110,57 @@ class BDDTrainer:
     def _train_segmentation_batch(self, batch):
         return hops.CrossEntropy2d.apply(self.model(batch["image"].to(self.device)), batch["mask"].to(self.device), 255)
 
-    def train_step(self, batch):
+    def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
         loss = self._train_detection_batch(batch) if self.task == "detection" else self._train_segmentation_batch(batch)
         loss.backward()
-        self.reducer.finish()
+        return loss
+
+    def _capture(self, batch):
+        self._static = {k: v.to(self.device).clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        self.reducer.paused = True  # hooks must not launch collectives inside the capture
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.reducer.enabled else "global"):
+                loss = self._fwd_bwd(self._static)
+            self._graph, self._static_loss = g, loss
+        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
+            import warnings
+            warnings.warn(f"hipGraph capture of the {self.task} train step failed ({e!r}); continuing without a graph")
+            self.use_graph, self._graph = False, None
+            torch.cuda.synchronize()
+        finally:
+            if self.reducer.enabled:  # graph and eager ranks issue different collectives: agree on one mode
+                ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    self._graph, self.use_graph = None, False
+            # once the ranks agreed on the graph, every later step -- replayed or (odd batch shape) eager -- exchanges gradients
+            # with the same single all-reduce, so ranks whose batches differ in shape still issue matching collectives
+            self.reducer.paused = self._graph is not None
+
+    def _fits_graph(self, batch) -> bool:
+        return all(isinstance(batch.get(k), torch.Tensor) and batch[k].shape == v.shape and batch[k].dtype == v.dtype
+                   for k, v in self._static.items())
+
+    def train_step(self, batch):
+        dev_ok = torch.device(self.device).type == "cuda"
+        if self.use_graph and dev_ok and self._graph is None and self._eager_steps >= 2 and self.core.training:
+            self._capture(batch)
+        if self._graph is not None and self.core.training and self._fits_graph(batch):
+            for k, v in self._static.items():
+                if batch[k].data_ptr() != v.data_ptr():
+                    v.copy_(batch[k], non_blocking=True)
+            self._graph.replay()
+            loss = self._static_loss
+            self.reducer.reduce_all()
+        elif self._graph is not None:
+            loss = self._fwd_bwd(batch)
+            self.reducer.reduce_all()
+        else:
+            loss = self._fwd_bwd(batch)
+            self.reducer.finish()
+            self._eager_steps += 1
         self.optimizer.step()  # clip_grad_norm_(1.0) folded in
         self.scheduler.step()
         return loss

@@ -636,3 +636,41 @@ def test_eval_bn_folding_matches_normalise_pass_and_torch(case):
             hc.FOLD_EVAL_BN = True
     assert rel_err(outs[True], outs[False]) < 2e-3
     assert rel_err(outs[True], yr) < 3e-3 and rel_err(outs[False], yr) < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(128, 256, 3, 2, 1, 4, 128, 160), (64, 128, 3, 1, 1, 2, 96, 128), (256, 512, 3, 1, 1, 4, 64, 64),
+                                  (128, 256, 1, 2, 0, 4, 128, 192), (512, 512, 3, 1, 1, 6, 46, 80)])
+def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
+    """Weight gradients whose contraction is long enough (>= 16384 output pixels, N % 128 == 0, output rows >= 32 pixels) run
+    the LDS-DMA ring kernel (conv_wgrad_ring.hip): against torch's conv2d weight gradient and against the register-staged
+    kernel (AM_WGRAD_RING=0 semantics via the module flag), including partial k-tiles, two n-tiles, stride 2 and 1x1."""
+    import ctypes
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, k, st, pad, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).requires_grad_()
+    y = F.conv2d(x, w, None, stride=st, padding=pad)
+    dyr = (torch.randn(y.shape, generator=g) * 0.5).half().float()
+    (y * dyr).sum().backward()
+    spec = hc.ConvSpec(cin, cout, k, st, pad)
+    xd, dyd = nhwc(x, torch.float16), nhwc(dyr, torch.float16)
+    geom = hc.fwd_geom(spec, B, H, W, cin, cout, 2)
+    assert B * geom.OH * geom.OW >= 16384 and geom.OW >= 32
+    outs = []
+    L = hc._L()
+    for ring in (1, 0):
+        dwp = torch.zeros(cout, geom.ntaps * geom.krun, dtype=torch.float32, device=_dev())
+        if ring:
+            hc.conv_wgrad(geom, xd, dyd, 1.0, dwp)
+        else:  # the same geometry with a 31-pixel-wide claim is not expressible: call the old kernel through a sub-16384 split
+            half = B // 2
+            for b0, nb in ((0, half), (half, B - half)):
+                gs = hc.fwd_geom(spec, nb, H, W, cin, cout, 2)
+                if nb * gs.OH * gs.OW >= 16384:
+                    pytest.skip("halves still long enough for the ring kernel")
+                hc.conv_wgrad(gs, xd[b0:b0 + nb].contiguous(), dyd[b0:b0 + nb].contiguous(), 1.0, dwp)
+        outs.append(hc.unpack_wgrad(dwp, spec, torch.float16).cpu())
+    assert rel_err(outs[0], w.grad) < 2e-3
+    assert rel_err(outs[0], outs[1]) < 1e-3
