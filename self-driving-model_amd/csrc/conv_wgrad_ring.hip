@@ -256,7 +256,7 @@ int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy,
   if (g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0 || g->MH != g->OH || g->MW != g->OW) return AM_ERR_UNSUPPORTED;  // GEMM row == output pixel
   if (g->MW < PS || (g->N % 128) != 0 || (g->y_coff * 2) % 16 != 0 || (g->ldo * 2) % 16 != 0 || (g->x_coff * 2) % 16 != 0) return AM_ERR_UNSUPPORTED;
   const long long M = (long long)g->B * g->MH * g->MW;
-  if (M < 16384) return AM_ERR_UNSUPPORTED;  // short contractions: the register-staged kernel's finer M split
+  if (M < 8192) return AM_ERR_UNSUPPORTED;  // short contractions: the register-staged kernel's finer M split
   const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
   const long long dy_bytes = M * g->ldo * 2;
   if (x_bytes >= (1ll << 31) || dy_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;

@@ -183,6 +183,9 @@ def dgrad_plans(s: ConvSpec, B: int, IH: int, IW: int, ld_dx: int, ld_dy: int, e
                 continue
             taps = [(kh, kw) for kh in range(s.k) for kw in range(s.k)
                     if (py + s.pad - kh) % st == 0 and (px + s.pad - kw) % st == 0]
+            # ascending (dy, dx): the input gradient of a 3x3 / stride-1 / pad-1 layer is then, tap for tap, the geometry of a
+            # forward 3x3 convolution and takes the kernels specialised for it (layer1: the weights-in-registers kernel)
+            taps.sort(key=lambda t: ((py + s.pad - t[0]) // st, (px + s.pad - t[1]) // st))
             g = _geom(B=B, MH=MH, MW=MW, IH=OH, IW=OW, ldi=ld_dy, x_coff=0, OH=IH, OW=IW, ldo=ld_dx, y_coff=0,
                       oys=st, oy0=py, oxs=st, ox0=px, iys=1, ixs=1, ntaps=len(taps), krun=ld_dy, pix_shift=31,
                       N=s.cin, dy=[(py + s.pad - kh) // st for kh, _ in taps], dx=[(px + s.pad - kw) // st for _, kw in taps])

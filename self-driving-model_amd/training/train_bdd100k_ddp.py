@@ -139,6 +139,12 @@ class BDDTrainer:
             # with the same single all-reduce, so ranks whose batches differ in shape still issue matching collectives
             self.reducer.paused = self._graph is not None
 
+    @property
+    def input_buffers(self):
+        """The captured step's static input tensors (None before the capture): a loader that writes its host-to-device
+        copies straight into them (and passes them to train_step) saves a device-to-device copy of the batch per step."""
+        return self._static if self._graph is not None else None
+
     def _fits_graph(self, batch) -> bool:
         return all(isinstance(batch.get(k), torch.Tensor) and batch[k].shape == v.shape and batch[k].dtype == v.dtype
                    for k, v in self._static.items())
