@@ -107,16 +107,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // tile `kk` = (tap, kin): A rows gather [tap offset + kin*64 B) of each pixel's run, B rows K bytes [kk*64, +64)
-  auto issue_tile = [&](int kk, int tap, int kin, int stage) {
+  // per-lane A offsets depend on the tap only (the K-step inside the tap goes into the scalar offset): recomputed when the
+  // tap changes, once per kpt K-steps, so a K-step's loader block is scalar arithmetic plus the loads
+  unsigned a_vo[AI];
+  auto tap_offsets = [&](int tap) {
     const int toff = __builtin_amdgcn_readlane(tapv, tap);
-    const unsigned uoff = (unsigned)(toff + kin * BKB);
+#pragma unroll
+    for (int j = 0; j < AI; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1u) ? a_off[j] + (unsigned)toff : OOB;
+  };
+  auto issue_tile = [&](int kk, int tap, int kin, int stage) {
     char* As = smem + stage * STAGE + wid * (AI * 1024);
     char* Bs = smem + stage * STAGE + BM * BKB + wid * (BI * 1024);
 #pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      const unsigned vo = ((a_mask[j] >> tap) & 1u) ? a_off[j] + uoff : OOB;
-      buffer_to_lds16(p.x, p.x_bytes, As + j * 1024, vo, 0);
-    }
+    for (int j = 0; j < AI; ++j) buffer_to_lds16(p.x, p.x_bytes, As + j * 1024, a_vo[j], kin * BKB);
 #pragma unroll
     for (int j = 0; j < BI; ++j)
       buffer_to_lds16(p.w, p.w_bytes, Bs + j * 1024, b_off[j], kk * BKB);
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     ikin = wrap ? 0 : ikin + 1;
     itap = wrap ? itap + 1 : itap;
   };
+  tap_offsets(0);
   issue_tile(ikk, itap, ikin, 0); advance();
+  if (ikin == 0) tap_offsets(itap);
   issue_tile(ikk, itap, ikin, 1); advance();
 
   // fragment read addressing: lane reads row (lane&31) of its 32-row sub-tile, 16-byte chunk (2*ks + lane>>5) ^ swz(row);
@@ -168,6 +173,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   for (int kk = 0; kk < nk; ++kk) {
     const char* S = smem + stage * STAGE;
     const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
+    // the previous half's fragment reads returned long ago (8 MFMAs back): waiting here, before the branch, keeps hipcc from
+    // putting an lgkmcnt(0) in front of this half's MFMAs once the reads below are in flight
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (ikin == 0) tap_offsets(itap);  // the tile requested below starts a new tap: its per-lane offsets
 #pragma unroll
     for (int t = 0; t < TM; ++t) a1[t] = *reinterpret_cast<const half8_t*>(S + fa[1] + t * 32 * BKB);
 #pragma unroll
