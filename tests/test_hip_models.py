@@ -978,3 +978,48 @@ def test_full_size_automoe_properties_b32_720p():
             assert int(sd[k]) == n0 + 6, (k, n0, int(sd[k]))  # six expert forwards: the prefetches replace, not add
         moved = [k for k, p in m.named_parameters() if p.requires_grad and not torch.equal(p.detach(), trainable0[k])]
         assert len(moved) == len(trainable0), set(trainable0) - set(moved)
+
+
+@pytest.mark.parametrize("task", ["detection", "drivable"])
+def test_bdd_trainer_hipgraph_matches_eager(task):
+    """BDDTrainer.train_step (training/train_bdd100k_ddp.py:89-100 glue: zero_grad -> forward -> loss -> backward -> clip +
+    AdamW -> cosine LR per step) captured into a hipGraph after two eager steps must walk the eager trajectory: detection
+    (matcher, assignment and scatter inside the capture, nothing synchronises the host) and drivable-area segmentation,
+    including a batch of another shape in between (runs eagerly, same single all-reduce path)."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.experts import BDDDetectionExpert, BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = _dev()
+    H, W = 128, 160
+    finals = {}
+    with runtime.precision(torch.float32):
+        for use_graph in (False, True):
+            torch.manual_seed(11)
+            m = (BDDDetectionExpert(10, pretrained_backbone=False) if task == "detection" else BDDDrivableExpert(3, pretrained_backbone=False)).to(dev).train()
+            if task == "detection":
+                b = synthetic.bdd_detection_batch(2, H, W, 10, 6, dev, seed=3)
+                odd = synthetic.bdd_detection_batch(1, H, W, 10, 6, dev, seed=4)
+            else:
+                b = synthetic.bdd_drivable_batch(2, H, W, 3, dev, seed=3)
+                odd = synthetic.bdd_drivable_batch(1, H, W, 3, dev, seed=4)
+            loader = synthetic.SyntheticLoader(b, 8)
+            tr = BDDTrainer(task, m, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t",
+                                                          "use_graph": use_graph})
+            losses = []
+            for i in range(7):
+                losses.append(float(tr.train_step(odd if i == 4 else b)))
+            assert (tr._graph is not None) == use_graph
+            finals[use_graph] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    np.testing.assert_allclose(finals[True][0], finals[False][0], rtol=5e-3, atol=1e-4)
+    # state after the seven steps, as one vector: seven AdamW steps (each moves a weight by ~lr whatever the gradient's size) on
+    # two images through train-mode BatchNorm amplify the fp32 atomics' summation order element by element (a ReLU that flips
+    # on a 1-ulp change moves every upstream gradient), so single elements of deep running statistics may differ by several
+    # per cent between ANY two runs; the losses above are the sharp check
+    fl = [k for k, v in finals[False][1].items() if v.dtype.is_floating_point]
+    va = torch.cat([finals[True][1][k].flatten().float() for k in fl])
+    vb = torch.cat([finals[False][1][k].flatten().float() for k in fl])
+    assert rel_err(va, vb) < 1e-2
+    for k, v in finals[False][1].items():
+        if not v.dtype.is_floating_point:
+            assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked
