@@ -98,11 +98,26 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"oracle AutoMoE 4a train step (torch-CPU fp32), B={B} 3x720x1280, median of {len(times)} steps after 1 warm-up"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a child; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config 4: 32)")
     ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / other_configs legs")
@@ -112,9 +127,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the reference's launcher line,
+        # training/train_gating_network.sh:111) as CHILD processes, before this process has made any GPU call, and relay
+        # rank 0's JSON line.  Never an exec: a process that touched the GPU must not be replaced.
+        raise SystemExit(spawn_ranks(args.gpus))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     local = local % max(torch.cuda.device_count(), 1)
     if distributed:

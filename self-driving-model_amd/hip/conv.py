@@ -420,8 +420,10 @@ class ConvBnAct(torch.autograd.Function):
                 # Inference (eval-mode BatchNorm, nothing wants a gradient): y = act(conv(x, w) * scale + shift) with constant
                 # scale / shift is the same convolution with weights w * scale[n] and bias shift[n] -- no normalise pass, no
                 # raw tensor.  The folded master weight is rebuilt only when a parameter or running statistic changed.
+                # FusedAdamW, am_bn_finalize and graph replays write parameters / running statistics through raw pointers (no
+                # tensor version bump): the runtime's weight / statistics epochs stand in for them
                 key = (w._version, w.data_ptr(), gamma._version, beta._version, bn.running_mean._version, bn.running_var._version,
-                       -1 if b is None else b._version, float(bn.eps))
+                       -1 if b is None else b._version, float(bn.eps), _runtime().weight_epoch(), _runtime().stats_epoch())
                 if cfg.cache.fold is None or cfg.cache.fold[0] != key:
                     sc = gamma.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
                     sh = beta.detach().float() - bn.running_mean.float() * sc
@@ -454,6 +456,8 @@ class ConvBnAct(torch.autograd.Function):
             upd = use_batch and bn.track_running_stats and bn.running_mean is not None
             rmean = ptr(bn.running_mean) if (upd or not use_batch) else None
             rvar = ptr(bn.running_var) if (upd or not use_batch) else None
+            if upd:
+                _runtime().bump_stats_epoch()
             if upd and bn.num_batches_tracked is not None:
                 PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # bumped together by flush_bn_counters()
             if fused_first:
@@ -511,6 +515,8 @@ class ConvBnAct(torch.autograd.Function):
             # the kernel accumulates (+=): in direct mode straight into the optimizer's gradient buffer
             L.am_bn_bwd_finalize(ptr(sums), AM_STATS_REPLICAS, float(P), ptr(gamma), ptr(rstd), inv,
                                  ptr(gp.grad) if direct else ptr(dgamma), ptr(bp.grad) if direct else ptr(dbeta), ptr(coef), cout, stream())
+            if direct:
+                _runtime().grad_ready(gp, bp)
             if not ctx.use_batch:
                 coef[cout:].zero_()  # eval-mode BN: statistics are constants
             fused_wgrad = False
@@ -626,6 +632,8 @@ def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
     L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
                      ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum),
                      float(bn.eps), 1, ptr(scale), ptr(shift), None, None, 64, stream())
+    if upd:
+        _runtime().bump_stats_epoch()
     if upd and bn.num_batches_tracked is not None:
         PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
     POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
@@ -667,6 +675,8 @@ def fused_basic_block_c64(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, 
         L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
                          ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum), float(bn.eps), 1,
                          ptr(scale), ptr(shift), None, None, 64, stream())
+        if upd:
+            _runtime().bump_stats_epoch()
         if upd and bn.num_batches_tracked is not None:
             PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
         return scale, shift
@@ -712,6 +722,8 @@ def _bn_finalize_nograd(bn, stats, P: int, C: int):
     _L().am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
                         ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum), float(bn.eps), 1,
                         ptr(scale), ptr(shift), None, None, C, stream())
+    if upd:
+        _runtime().bump_stats_epoch()
     if upd and bn.num_batches_tracked is not None:
         PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
     return scale, shift

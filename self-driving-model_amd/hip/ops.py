@@ -277,6 +277,7 @@ class LinearAct(torch.autograd.Function):
                 # the kernel accumulates (+=): straight into the optimizer's gradient buffer, nothing for autograd to add
                 _L().am_linear_bwd_weight(ptr(dy), N, ptr(y), N, ptr(x), K, ptr(Wp.grad), ptr(bp.grad) if ctx.has_b else None,
                                           M, N, K, stream())
+                _runtime().grad_ready(Wp, bp if ctx.has_b else None)
                 return dx, None, None, None
             dW = torch.zeros_like(W)
             db = torch.zeros(N, dtype=torch.float32, device=W.device) if ctx.has_b else None
@@ -308,6 +309,7 @@ class LayerNormFn(torch.autograd.Function):
         gp, bp = ctx.params
         if _runtime().direct_grads() and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _grad_ready(gp) and _grad_ready(bp):
             _L().am_layernorm_bwd(ptr(dy), D, ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), D, ptr(gp.grad), ptr(bp.grad), M, D, stream())
+            _runtime().grad_ready(gp, bp)
             return dx, None, None, None
         dg = torch.zeros_like(gamma) if need_p else None
         db = torch.zeros_like(gamma) if need_p else None

@@ -250,7 +250,16 @@ class AutoMoE(nn.Module):
             if path and path != "":
                 try:
                     checkpoint = torch.load(path, map_location=self.device, weights_only=True)
-                    expert.load_state_dict(checkpoint.get("model_state_dict", checkpoint))
+                    state_dict = checkpoint.get("model_state_dict", checkpoint)
+                    if isinstance(expert, NuScenesExpert):
+                        # checkpoints of the older NuScenes expert name its query MLP `mlp.` and its box head `box_head.`
+                        # (reference automoe.py:251-262): remapped, and loaded non-strictly as the reference does
+                        state_dict = {("decoder." + k[len("mlp."):] if k.startswith("mlp.") else
+                                       "bbox_head." + k[len("box_head."):] if k.startswith("box_head.") else k): v
+                                      for k, v in state_dict.items()}
+                        expert.load_state_dict(state_dict, strict=False)
+                    else:
+                        expert.load_state_dict(state_dict)
                     print(f"Loaded checkpoint for expert {i}: {path}")
                 except Exception as e:  # noqa: BLE001
                     warnings.warn(f"Failed to load checkpoint for expert {i}: {e}")

@@ -19,7 +19,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
-_STATE = {"dtype": torch.float16, "loss_scale": 16384.0, "weight_epoch": 0}
+_STATE = {"dtype": torch.float16, "loss_scale": 16384.0, "weight_epoch": 0, "stats_epoch": 0}
 
 
 def compute_dtype() -> torch.dtype:
@@ -67,6 +67,32 @@ def direct_grads() -> bool:
     return _DIRECT_GRADS
 
 
+# Listeners told that a parameter's gradient is complete for this backward (training/ddp.py GradBucketReducer).  autograd's
+# post-accumulate hooks cover parameters whose gradient autograd accumulates; a backward kernel that added straight into
+# ``param.grad`` (direct mode) reports it here instead, so the bucketed all-reduce sees every parameter exactly once.
+_GRAD_LISTENERS = []
+
+
+def add_grad_listener(cb) -> None:
+    import weakref
+    _GRAD_LISTENERS.append(weakref.WeakMethod(cb) if hasattr(cb, "__self__") else (lambda: cb))
+
+
+def grad_ready(*params) -> None:
+    if not _GRAD_LISTENERS:
+        return
+    alive = []
+    for ref in _GRAD_LISTENERS:
+        cb = ref()
+        if cb is None:
+            continue
+        alive.append(ref)
+        for p in params:
+            if p is not None:
+                cb(p)
+    _GRAD_LISTENERS[:] = alive
+
+
 def loss_scale() -> float:
     return _STATE["loss_scale"] if _STATE["dtype"] == torch.float16 else 1.0
 
@@ -83,6 +109,17 @@ def weight_epoch() -> int:
 
 def bump_weight_epoch():
     _STATE["weight_epoch"] += 1
+
+
+def stats_epoch() -> int:
+    """Bumped whenever BatchNorm running statistics may have been updated through raw pointers: by every train-mode
+    am_bn_finalize issued from Python and by every replay of a captured train step (a replay runs no Python).  Caches of
+    anything derived from the running statistics (the eval-mode conv+BN fold, hip/conv.py) key on it."""
+    return _STATE["stats_epoch"]
+
+
+def bump_stats_epoch():
+    _STATE["stats_epoch"] += 1
 
 
 @contextlib.contextmanager

@@ -1,40 +1,63 @@
 """Data-parallel gradient exchange for one process per GPU (the reference wraps its model in
 torch DistributedDataParallel: training/train_bdd100k_ddp.py:497, training/train_gating_network.py:236).
 
-One RCCL all-reduce (sum) per gradient bucket over xGMI, issued from autograd hooks as soon as every
-gradient in the bucket has been accumulated, on a side HIP stream that waits on an event recorded on
-the compute stream -- so the exchange overlaps the rest of backward.  Buckets are contiguous slices of
-the optimizer's flat gradient buffer (training/optim.py) filled in reverse parameter order, the order
-backward produces them.  The mean (divide by world size) is folded into the optimizer's scale pass.
-BatchNorm buffers stay rank-local (the reference's per-forward buffer broadcast changes nothing for rank 0).
-Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU tensors in tests.
+One RCCL all-reduce (sum) per gradient bucket over xGMI, issued as soon as every gradient in the bucket is
+complete, on a side HIP stream that waits on an event recorded on the compute stream -- so the exchange
+overlaps the rest of backward.  Buckets are contiguous slices of the optimizer's flat gradient buffer
+(training/optim.py) filled in reverse parameter order, the order backward produces them.  The mean (divide by
+world size) is folded into the optimizer's scale pass.  BatchNorm buffers stay rank-local (the reference's
+per-forward buffer broadcast changes nothing for rank 0).
+
+"Gradient complete" comes from two sources, each parameter reporting exactly once per backward: autograd's
+post-accumulate hook (gradients autograd accumulates: conv weights / biases) and runtime.grad_ready() from the
+backward kernels that add straight into ``param.grad`` (Linear / LayerNorm / BatchNorm parameters in direct
+mode, hip/ops.py, hip/conv.py).
+
+hipGraph steps: with the "nccl" backend (= RCCL on ROCm) the bucket collectives are CAPTURED with the step --
+event record on the compute stream, wait + all-reduce on the side stream, join before the optimizer -- so a
+replay exchanges each bucket beside the rest of backward exactly as the eager step does.  Backends that cannot
+be captured ("gloo" in the CPU / shared-GPU tests) keep the hooks silent during the capture (`paused`) and run
+ONE all-reduce over the flat buffer after the replay (`reduce_all`).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
+from .. import runtime
+
 
 class GradBucketReducer:
     def __init__(self, params: List[torch.nn.Parameter], offsets: List[int], flat_grad: torch.Tensor,
-                 bucket_bytes: int = 25 * 1024 * 1024, process_group=None, broadcast_from: Optional[torch.Tensor] = None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
-        self.world = dist.get_world_size(process_group) if self.enabled else 1
+                 bucket_bytes: Optional[int] = None, process_group=None, broadcast_from: Optional[torch.Tensor] = None,
+                 force: Optional[bool] = None):
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("AUTOMOE_BUCKET_MB", "25")) * 1024 * 1024)
+        if force is None:  # tests: run the bucket machinery on a 1-rank group (one GPU box, RCCL itself still executes)
+            force = os.environ.get("AUTOMOE_DDP_FORCE", "0") == "1"
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if live else 1
+        self.enabled = live and (self.world > 1 or force)
         self.pg = process_group
         self.flat = flat_grad
         self.buckets = []  # (start, end, n_params)
         self._bucket_of = {}
+        self._index = {}
         self._pending, self._handles = [], []
-        self.paused = False  # True while a hipGraph owns backward: hooks stay silent, reduce_all() runs after the replay
+        self.paused = False  # True while a hipGraph without captured collectives owns backward: reduce_all() runs after the replay
         self.side = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # collectives of this backend can be recorded into a hipGraph (c10d's NCCL work is stream-ordered; gloo's is host-side)
+        self.capturable = bool(self.enabled and flat_grad.is_cuda and dist.get_backend(process_group) == "nccl"
+                               and os.environ.get("AUTOMOE_GRAPH_ALLREDUCE", "1") != "0")
         if not self.enabled:
             return
         if broadcast_from is not None:  # DDP constructor semantics: rank 0's parameters everywhere
             dist.broadcast(broadcast_from, src=0, group=process_group)
         order = sorted(range(len(params)), key=lambda i: offsets[i], reverse=True)
-        cur_hi, cur_lo, count = None, None, 0
+        cur_hi, cur_lo = None, None
         members = []
         for i in order:
             lo, hi = offsets[i], offsets[i] + params[i].numel()
@@ -42,14 +65,16 @@ class GradBucketReducer:
                 cur_hi = hi
             cur_lo = lo
             members.append(i)
-            count += 1
             if (cur_hi - cur_lo) * 4 >= bucket_bytes:
                 self._close(cur_lo, cur_hi, members)
-                cur_hi, members, count = None, [], 0
+                cur_hi, members = None, []
         if members:
             self._close(cur_lo, cur_hi, members)
         for i, p in enumerate(params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+            self._index[id(p)] = i
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        self._params = params  # keeps id() keys valid
+        runtime.add_grad_listener(self._on_grad)
         self.reset()
 
     def _close(self, lo, hi, members):
@@ -63,17 +88,20 @@ class GradBucketReducer:
         self._handles = []
         self._streams = [set() for _ in self.buckets]  # streams whose backward nodes wrote into each bucket
 
-    def _make_hook(self, idx):
-        def hook(_param):
-            if self.paused:
-                return
-            b = self._bucket_of[idx]
-            if self.flat.is_cuda:
-                self._streams[b].add(torch.cuda.current_stream())
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
-        return hook
+    def _on_grad(self, param):
+        """`param`'s gradient for this backward is complete in the flat buffer (autograd hook or runtime.grad_ready)."""
+        if self.paused or not self.enabled:
+            return
+        idx = self._index.get(id(param))
+        if idx is None:
+            return
+        b = self._bucket_of[idx]
+        if self.flat.is_cuda:
+            self._streams[b].add(torch.cuda.current_stream())
+        self._pending[b] -= 1
+        assert self._pending[b] >= 0, "a parameter reported its gradient twice in one backward"
+        if self._pending[b] == 0:
+            self._launch(b)
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
@@ -95,14 +123,14 @@ class GradBucketReducer:
             self._handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def reduce_all(self):
-        """One all-reduce over the whole flat gradient buffer (used after a graph replay, where per-bucket hooks did not run)."""
+        """One all-reduce over the whole flat gradient buffer (after a graph replay whose capture held no collectives)."""
         if not self.enabled:
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self):
-        """Block the compute stream until every bucket is reduced; buckets whose hooks never fired (unused
-        parameters) are reduced here so all ranks stay in step."""
+        """Block the compute stream until every bucket is reduced; buckets that never completed (unused
+        parameters) are reduced here so all ranks stay in step.  Inside a capture this records the joins."""
         if not self.enabled:
             return
         for b, left in enumerate(self._pending):
@@ -113,6 +141,58 @@ class GradBucketReducer:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         self.reset()
+
+    # ---- protocol shared by the trainers' hipGraph steps ---------------------------------------------------------
+    def capture_begin(self) -> bool:
+        """Call before capturing a step.  True: the capture records the bucket collectives (call finish() inside it, after
+        backward); False: hooks are silenced for the capture and every step ends with reduce_all()."""
+        in_graph = self.enabled and self.capturable
+        self.paused = self.enabled and not in_graph
+        self.reset()
+        return in_graph
+
+    def agree(self, mode: int) -> int:
+        """Ranks must issue matching collectives: MIN over ranks of the step mode each one reached
+        (2 graph with captured collectives, 1 graph + reduce_all, 0 eager)."""
+        if not self.enabled:
+            return mode
+        t = torch.tensor([mode], device=self.flat.device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+        return int(t.item())
+
+
+def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step"):
+    """Capture one training step into a hipGraph in the best mode every rank can reach.
+
+    capture_fn(in_graph) -> (graph, result) captures zero_grad + forward + loss + backward and, when `in_graph`, the
+    reducer's finish() (bucket collectives recorded with the step).  Returns (graph, result, in_graph); graph is None when
+    the step stays eager.  Ranks agree after every attempt (a rank whose capture failed pulls all of them one mode down),
+    so every rank issues the same collectives afterwards."""
+    import traceback
+    import warnings
+    want = 2 if reducer.capture_begin() else 1
+    graph = result = None
+    while want > 0:
+        reducer.paused = reducer.enabled and want == 1
+        reducer.reset()
+        got = want
+        try:
+            graph, result = capture_fn(want == 2)
+        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back, loudly)
+            warnings.warn(f"hipGraph capture of the {what} failed in mode {want} ({e!r})\n"
+                          + "".join(traceback.format_exc().splitlines(True)[-14:]))
+            graph = result = None
+            got = want - 1
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        agreed = reducer.agree(got)
+        if agreed == want:
+            break
+        want, graph, result = agreed, None, None
+    in_graph = graph is not None and want == 2
+    reducer.paused = reducer.enabled and graph is not None and not in_graph
+    reducer.reset()
+    return graph, result, in_graph
 
 
 class DataParallel(torch.nn.Module):

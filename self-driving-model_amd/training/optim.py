@@ -82,15 +82,35 @@ class FusedAdamW(torch.optim.Optimizer):
         return self.norm_sq.sqrt().float()
 
     def state_dict(self):
+        """torch.optim.AdamW's layout -- state[i] = {'step', 'exp_avg', 'exp_avg_sq'} per parameter index, sliced out of the
+        flat moment buffers -- so a checkpoint written here resumes under the reference's torch AdamW
+        (train_bdd100k_ddp.py:536-545 `--resume_mode full`) and the reverse."""
         sd = super().state_dict()
-        sd["fused"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count}
+        if self.step_count > 0:
+            step = torch.tensor(float(self.step_count))
+            sd["state"] = {i: {"step": step.clone(), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                               "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+                           for i, (p, o) in enumerate(zip(self._params, self._offsets))}
         return sd
 
     def load_state_dict(self, state_dict):
-        fused = state_dict.get("fused")
-        base = {k: v for k, v in state_dict.items() if k != "fused"}
-        super().load_state_dict(base)
+        fused = state_dict.get("fused")  # round-1 checkpoints of this build: the flat buffers as they are
+        state = state_dict.get("state") or {}
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if fused is not None:
             self.exp_avg.copy_(fused["exp_avg"])
             self.exp_avg_sq.copy_(fused["exp_avg_sq"])
             self.step_count = int(fused["step"])
+            return
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+        for i, (p, o) in enumerate(zip(self._params, self._offsets)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue  # torch creates a parameter's state lazily: no entry = never stepped
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: exp_avg shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
+            self.exp_avg[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+            self.step_count = max(self.step_count, int(float(st["step"])))  # one bias-correction count for the fused pass

@@ -17,10 +17,11 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import runtime
 from ..hip import ops as hops
 from ..models.experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer
+from .ddp import DataParallel, GradBucketReducer, capture_step
 from .hungarian_matcher import HungarianMatcher
 from .optim import FusedAdamW
 
@@ -91,6 +92,7 @@ class BDDTrainer:
         # different GT padding) run eagerly.
         self.use_graph = os.environ.get("AUTOMOE_HIPGRAPH", "1") != "0" if config.get("use_graph") is None else bool(config["use_graph"])
         self._graph = self._static = self._static_loss = None
+        self._reduce_in_graph = False
         self._eager_steps = 0
 
     def load_training_state(self, checkpoint):
@@ -118,26 +120,21 @@ class BDDTrainer:
 
     def _capture(self, batch):
         self._static = {k: v.to(self.device).clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
-        self.reducer.paused = True  # hooks must not launch collectives inside the capture
-        try:
+        mode = "thread_local" if self.reducer.enabled else "global"
+
+        def capture(in_graph):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.reducer.enabled else "global"):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 loss = self._fwd_bwd(self._static)
-            self._graph, self._static_loss = g, loss
-        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
-            import warnings
-            warnings.warn(f"hipGraph capture of the {self.task} train step failed ({e!r}); continuing without a graph")
-            self.use_graph, self._graph = False, None
-            torch.cuda.synchronize()
-        finally:
-            if self.reducer.enabled:  # graph and eager ranks issue different collectives: agree on one mode
-                ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    self._graph, self.use_graph = None, False
-            # once the ranks agreed on the graph, every later step -- replayed or (odd batch shape) eager -- exchanges gradients
-            # with the same single all-reduce, so ranks whose batches differ in shape still issue matching collectives
-            self.reducer.paused = self._graph is not None
+                if in_graph:
+                    self.reducer.finish()  # RCCL bucket all-reduces recorded with the step (training/ddp.py)
+            return g, loss
+
+        # once the ranks agreed on a mode, every later step -- replayed or (odd batch shape) eager -- exchanges gradients with
+        # the same collectives, so ranks whose batches differ in shape still match
+        self._graph, self._static_loss, self._reduce_in_graph = capture_step(self.reducer, capture, f"{self.task} train step")
+        if self._graph is None:
+            self.use_graph = False
 
     @property
     def input_buffers(self):
@@ -158,11 +155,17 @@ class BDDTrainer:
                 if batch[k].data_ptr() != v.data_ptr():
                     v.copy_(batch[k], non_blocking=True)
             self._graph.replay()
+            runtime.bump_stats_epoch()  # the replay updated BatchNorm running statistics without running Python
             loss = self._static_loss
-            self.reducer.reduce_all()
+            if not self._reduce_in_graph:
+                self.reducer.reduce_all()
         elif self._graph is not None:
+            self.reducer.reset()
             loss = self._fwd_bwd(batch)
-            self.reducer.reduce_all()
+            if self._reduce_in_graph:
+                self.reducer.finish()
+            else:
+                self.reducer.reduce_all()
         else:
             loss = self._fwd_bwd(batch)
             self.reducer.finish()

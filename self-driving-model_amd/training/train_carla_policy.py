@@ -18,7 +18,7 @@ import torch.distributed as dist
 from .. import runtime
 from ..models.policy.trajectory_head import TrajectoryPolicy
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer
+from .ddp import DataParallel, GradBucketReducer, capture_step
 from .optim import FusedAdamW
 
 
@@ -52,11 +52,12 @@ class PolicyTrainStep:
         self.optimizer.grad_divisor = float(self.reducer.world)
         self.use_graph = (os.environ.get("AUTOMOE_HIPGRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         self._graph = self._static = self._static_losses = None
+        self._reduce_in_graph = False
         self._eager_steps = 0
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
-        runtime.set_direct_grads(not self.reducer.enabled or self.reducer.paused)
+        runtime.set_direct_grads(True)  # the direct kernels report to the reducer through runtime.grad_ready()
         try:
             losses = fused_losses(self.model(batch["image"], batch.get("context")), batch["waypoints"], batch["speed"])
             losses["loss"].backward()
@@ -66,35 +67,43 @@ class PolicyTrainStep:
 
     def _capture(self, batch):
         self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        self.reducer.paused = True
-        try:
+        mode = "thread_local" if self.reducer.enabled else "global"
+
+        def capture(in_graph):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.reducer.enabled else "global"):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 losses = self._fwd_bwd(self._static)
-            self._graph, self._static_losses = g, losses
-        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
-            import warnings
-            warnings.warn(f"hipGraph capture of the policy train step failed ({e!r}); continuing without a graph")
-            self.use_graph, self._graph = False, None
-            torch.cuda.synchronize()
-        finally:
-            if self.reducer.enabled:
-                ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    self._graph, self.use_graph = None, False
-            self.reducer.paused = self._graph is not None
+                if in_graph:
+                    self.reducer.finish()
+            return g, losses
+
+        self._graph, self._static_losses, self._reduce_in_graph = capture_step(self.reducer, capture, "policy train step")
+        if self._graph is None:
+            self.use_graph = False
+
+    def _fits_graph(self, batch) -> bool:
+        return all(isinstance(batch.get(k), torch.Tensor) and batch[k].shape == v.shape and batch[k].dtype == v.dtype
+                   for k, v in self._static.items() if isinstance(v, torch.Tensor))
 
     def __call__(self, batch):
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.core.training:
             self._capture(batch)
-        if self._graph is not None:
+        if self._graph is not None and self._fits_graph(batch):
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor) and v.data_ptr() != self._static[k].data_ptr():
                     self._static[k].copy_(v, non_blocking=True)
             self._graph.replay()
+            runtime.bump_stats_epoch()
             losses = self._static_losses
-            self.reducer.reduce_all()
+            if not self._reduce_in_graph:
+                self.reducer.reduce_all()
+        elif self._graph is not None:  # ragged batch after the capture: eager, same collectives as the replaying ranks
+            self.reducer.reset()
+            losses = self._fwd_bwd(batch)
+            if self._reduce_in_graph:
+                self.reducer.finish()
+            else:
+                self.reducer.reduce_all()
         else:
             losses = self._fwd_bwd(batch)
             self.reducer.finish()

@@ -19,7 +19,7 @@ import torch.nn.functional as F  # noqa: F401  (kept for API parity with the ref
 from .. import runtime
 from ..models.automoe import create_automoe_model
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer
+from .ddp import DataParallel, GradBucketReducer, capture_step
 from .optim import FusedAdamW
 
 
@@ -90,8 +90,11 @@ class GatingTrainStep:
     With `use_graph` (default: env AUTOMOE_HIPGRAPH, on) the launch-bound part of the step -- zero_grad, forward,
     losses, backward: ~900 small launches -- is captured once into a hipGraph (torch.cuda.CUDAGraph over our kernels,
     which run on the capturing stream) and replayed; the gradient exchange and the fused optimizer stay outside the
-    graph so the learning rate / step count remain host-driven.  Under a graph the gradient all-reduce is issued as one
-    collective after the replay instead of per bucket from hooks (11.5 MB in the reference's frozen-expert stage)."""
+    graph so the learning rate / step count remain host-driven.  With RCCL ("nccl") the per-bucket all-reduces are part
+    of the captured step (side stream, beside the rest of backward: training/ddp.py); a backend that cannot be captured
+    ("gloo" in tests) gets one collective after the replay instead.  A batch whose tensor shapes differ from the captured
+    ones (the reference's gating loader has no drop_last: training/train_gating_network.py:259-267) runs eagerly with the
+    same collectives."""
 
     def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = 25, use_graph=None):
         self.model = model
@@ -111,6 +114,7 @@ class GatingTrainStep:
         self._graph = None
         self._static_batch = None
         self._static_losses = None
+        self._reduce_in_graph = False   # the captured step holds its bucket all-reduces (RCCL)
         self._eager_steps = 0
         # Expert prefetch (frozen experts only): the experts' forward is its own hipGraph on its own stream and runs for the
         # NEXT batch while the rest of this step -- gating / policy forward, backward, all-reduce, optimizer: kernels that
@@ -126,9 +130,9 @@ class GatingTrainStep:
 
     def _fwd_bwd(self, batch, expert_cache=None):
         self.optimizer.zero_grad()
-        # parameter gradients go straight into the flat buffer unless the bucketed all-reduce is listening to autograd's
-        # accumulate hooks (eager multi-rank mode)
-        runtime.set_direct_grads(not self.reducer.enabled or self.reducer.paused)
+        # Linear / LayerNorm / BatchNorm parameter gradients go straight into the flat buffer; their kernels' call sites tell
+        # the bucketed all-reduce when one is complete (runtime.grad_ready), autograd's hooks cover the rest
+        runtime.set_direct_grads(True)
         try:
             pred = self.model(batch) if expert_cache is None else self.model(batch, expert_cache=expert_cache)
             losses = fused_gating_losses(pred, batch["waypoints"], batch["speed"], self.config)
@@ -139,11 +143,10 @@ class GatingTrainStep:
 
     def _capture(self, batch):
         self._static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        self.reducer.paused = True  # hooks must not launch collectives inside the capture
+        # with a process group alive its watchdog thread touches the runtime concurrently: only police this thread
+        mode = "thread_local" if self.reducer.enabled else "global"
+        cache_b = None
         try:
-            # with a process group alive its watchdog thread touches the runtime concurrently: only police this thread
-            mode = "thread_local" if self.reducer.enabled else "global"
-            cache_b = None
             if (self.prefetch_experts and hasattr(self.core, "forward_experts") and self.core.fuse_expert_pooling
                     and self.core.experts_frozen() and batch["image"].is_cuda):
                 self._expert_stream = torch.cuda.Stream(device=batch["image"].device)
@@ -180,26 +183,27 @@ class GatingTrainStep:
                 torch.cuda.synchronize()
                 for b, v in zip(bufs, saved):
                     b.copy_(v)
+        except Exception as e:  # noqa: BLE001  (the prefetch is an optimisation: go on without it, loudly)
+            import traceback
+            import warnings
+            warnings.warn(f"hipGraph capture of the expert prefetch failed ({e!r}); continuing without it\n"
+                          + "".join(traceback.format_exc().splitlines(True)[-14:]))
+            self._graph_experts, cache_b = None, None
+            torch.cuda.synchronize()
+
+        def capture(in_graph):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=mode):
                 losses = self._fwd_bwd(self._static_batch, cache_b)
-            self._graph, self._static_losses = g, losses
-        except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager, loudly)
-            import traceback
-            import warnings
-            warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing without a graph\n"
-                          + "".join(traceback.format_exc().splitlines(True)[-14:]))
+                if in_graph:
+                    self.reducer.finish()  # records the joins: the replay ends with every bucket reduced
+            return g, losses
+
+        # (ranks agree on one mode inside capture_step: graph and eager ranks would otherwise issue different collectives)
+        self._graph, self._static_losses, self._reduce_in_graph = capture_step(self.reducer, capture, "gating train step")
+        if self._graph is None:
             self.use_graph = False
-            self._graph = self._graph_experts = None
-            torch.cuda.synchronize()
-        finally:
-            if self.reducer.enabled:
-                # graph and eager ranks issue different collectives: agree on one mode or deadlock
-                ok = torch.tensor([1 if self._graph is not None else 0], device=self.optimizer.flat_g.device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    self._graph, self._graph_experts, self.use_graph = None, None, False
-            self.reducer.paused = self._graph is not None
+            self._graph_experts = None
 
     @property
     def input_buffers(self):
@@ -207,23 +211,51 @@ class GatingTrainStep:
         copies straight into them (or passes them back to ``__call__``) saves the per-step device-to-device copy."""
         return self._static_batch if self._graph is not None else None
 
-    def _launch_experts(self, batch):
-        """Graph A for `batch` on the expert stream (after the previous step's copy of its results has been taken)."""
+    def _fits_graph(self, batch) -> bool:
+        """`batch` has the captured step's tensor shapes / dtypes (a ragged last batch does not)."""
+        return all(isinstance(batch.get(k), torch.Tensor) and batch[k].shape == v.shape and batch[k].dtype == v.dtype
+                   for k, v in self._static_batch.items() if isinstance(v, torch.Tensor))
+
+    def _launch_experts(self, batch) -> bool:
+        """Graph A for `batch` on the expert stream (after the previous step's copy of its results has been taken).
+        False (nothing launched) when the batch's image does not have the captured shape."""
+        if batch is not True:  # True: the caller's loader already wrote the batch into expert_input_buffers
+            img = batch.get("image") if isinstance(batch, dict) else None
+            ref = self._expert_batch["image"]
+            if not isinstance(img, torch.Tensor) or img.shape != ref.shape or img.dtype != ref.dtype:
+                return False
         st = self._expert_stream
         st.wait_event(self._ev_copied)  # (never recorded yet: no-op)
         with torch.cuda.stream(st):
-            if batch is not True:  # True: the caller's loader already wrote the batch into expert_input_buffers
-                img = batch["image"]
-                if img.data_ptr() != self._expert_batch["image"].data_ptr():
-                    self._expert_batch["image"].copy_(img, non_blocking=True)
+            if batch is not True and batch["image"].data_ptr() != self._expert_batch["image"].data_ptr():
+                self._expert_batch["image"].copy_(batch["image"], non_blocking=True)
             self._graph_experts.replay()
+            runtime.bump_stats_epoch()  # frozen experts still update their BatchNorm running statistics (train mode)
             self._ev_experts.record(st)
+        return True
 
     @property
     def expert_input_buffers(self):
         """Graph A's static input ({"image": ...}) when the expert prefetch is active (else None): where a loader puts the
         NEXT batch's image, to be passed as ``next_batch`` without a device-to-device copy."""
         return self._expert_batch if self._graph_experts is not None and self._graph is not None else None
+
+    def _eager_step_beside_graph(self, batch):
+        """A batch the captured step cannot take, after the capture: the same step eagerly, exchanging gradients with the
+        collectives the replaying ranks issue (per bucket when they are part of the graph, else the single all-reduce)."""
+        if self._graph_experts is not None:
+            main = torch.cuda.current_stream()
+            main.wait_event(self._ev_experts)  # the experts' BatchNorm buffers: a pending prefetch finishes first
+        self.reducer.paused = self.reducer.enabled and not self._reduce_in_graph
+        self.reducer.reset()
+        losses = self._fwd_bwd(batch)
+        if self._reduce_in_graph:
+            self.reducer.finish()
+        else:
+            self.reducer.reduce_all()
+        if self._graph_experts is not None:
+            self._ev_copied.record(torch.cuda.current_stream())  # the next prefetch waits for this step's expert forward
+        return losses
 
     def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One step on `batch`.  `next_batch` (optional): the batch of the NEXT call -- a dict with its "image", or True when
@@ -232,7 +264,7 @@ class GatingTrainStep:
         launched now and overlaps this step's backward / optimizer; the next call must then be made with exactly that batch."""
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:
             self._capture(batch)
-        if self._graph is not None:
+        if self._graph is not None and self._fits_graph(batch):
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
                     self._static_batch[k].copy_(v, non_blocking=True)
@@ -245,11 +277,18 @@ class GatingTrainStep:
                 self._ev_copied.record(main)
                 self._experts_pending = False
             self._graph.replay()
+            runtime.bump_stats_epoch()
             losses = self._static_losses
             if self._graph_experts is not None and next_batch is not None:
-                self._launch_experts(next_batch)
-                self._experts_pending = True
-            self.reducer.reduce_all()
+                self._experts_pending = self._launch_experts(next_batch)
+            if not self._reduce_in_graph:
+                self.reducer.reduce_all()
+        elif self._graph is not None:
+            # ragged batch (a prefetch launched for it would have been refused by _launch_experts: nothing is pending)
+            self._experts_pending = False
+            losses = self._eager_step_beside_graph(batch)
+            if self._graph_experts is not None and next_batch is not None:
+                self._experts_pending = self._launch_experts(next_batch)
         else:
             losses = self._fwd_bwd(batch)
             self.reducer.finish()

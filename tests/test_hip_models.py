@@ -1023,3 +1023,122 @@ def test_bdd_trainer_hipgraph_matches_eager(task):
     for k, v in finals[False][1].items():
         if not v.dtype.is_floating_point:
             assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_eval_bn_fold_follows_training(use_graph):
+    """The eval-mode conv+BatchNorm fold (hip/conv.py FOLD_EVAL_BN) is a cache of the weights AND the running statistics.
+    FusedAdamW, am_bn_finalize and hipGraph replays update both through raw pointers (no tensor version bump), so the
+    cache keys on runtime.weight_epoch() / stats_epoch(): validate() after further train steps -- eager or replayed -- must
+    evaluate the CURRENT model (train_bdd100k_ddp.py:197-335 picks best.pth by that loss).  Checked against the unfolded
+    normalise pass on the same weights and against the oracle loaded with the trained state_dict."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.models.experts import BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    from oracle import torch_ref as oref
+    dev = _dev()
+    H, W = 128, 160
+    torch.manual_seed(21)
+    m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
+    b = synthetic.bdd_drivable_batch(2, H, W, 3, dev, seed=5)
+    loader = synthetic.SyntheticLoader(b, 8)
+    x = seeded_tensor((2, 3, H, W), 22).to(dev)
+
+    def evaluate():
+        m.eval()
+        with torch.no_grad(), runtime.precision(torch.float16):
+            y = m(x).float().cpu()
+        m.train()
+        return y
+
+    with runtime.precision(torch.float16):
+        tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 5e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t",
+                                                              "use_graph": use_graph})
+        y0 = evaluate()  # fills every fold cache with the initial weights / running statistics
+        for _ in range(5):  # two eager steps, then (use_graph) the capture and replays
+            tr.train_step(b)
+        assert (tr._graph is not None) == use_graph
+        y1 = evaluate()
+        saved = hc.FOLD_EVAL_BN
+        hc.FOLD_EVAL_BN = False
+        try:
+            y1_unfolded = evaluate()
+        finally:
+            hc.FOLD_EVAL_BN = saved
+    assert rel_err(y1, y0) > 5e-2, "five steps at lr 5e-3 must move the logits"
+    assert rel_err(y1, y1_unfolded) < 1e-2, rel_err(y1, y1_unfolded)  # f16 rounding of folded vs separately normalised
+    ref = oref.BDDDrivableExpert(3, False)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}, strict=True)
+    ref.eval()
+    with torch.no_grad():
+        yr = ref(x.cpu())
+    assert rel_err(y1, yr) < 2e-2, rel_err(y1, yr)
+
+
+def test_optimizer_state_and_nuscenes_keys_in_the_reference_layout(tmp_path):
+    """Checkpoint compatibility beyond the weights (train_bdd100k_ddp.py:401-420 saves `optimizer_state_dict` of a torch
+    AdamW; :536-545 `--resume_mode full` loads it; automoe.py:251-262 remaps old NuScenes keys): (1) a torch.optim.AdamW
+    state_dict loads into FusedAdamW and the next step of both optimizers lands on the same parameters; (2) FusedAdamW's
+    state_dict loads into torch.optim.AdamW; (3) a NuScenes checkpoint keyed `mlp.` / `box_head.` loads through
+    load_expert_checkpoints.  Everything goes through torch.load(weights_only=True)."""
+    from oracle import torch_ref as oref
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.models.policy.trajectory_head import TrajectoryPolicy
+    from self_driving_model_amd.training.optim import FusedAdamW
+    dev = _dev()
+    ref = seed_module_(oref.TrajectoryPolicy(10, 256), 61)
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    grads = [[seeded_tensor(tuple(p.shape), 700 + 10 * s + i) * 0.01 for i, p in enumerate(ref.parameters())] for s in range(3)]
+    for s in range(2):  # two torch steps build a non-trivial state
+        for p, g in zip(ref.parameters(), grads[s]):
+            p.grad = g.clone()
+        opt_r.step()
+    torch.save({"model_state_dict": ref.state_dict(), "optimizer_state_dict": opt_r.state_dict()}, tmp_path / "ck.pth")
+    ck = torch.load(tmp_path / "ck.pth", map_location=dev, weights_only=True)
+    hip = TrajectoryPolicy(10, 256)
+    hip.load_state_dict(ck["model_state_dict"], strict=True)
+    hip.to(dev)
+    opt_h = FusedAdamW(hip.parameters(), lr=1e-3, weight_decay=1e-2, max_norm=0.0)
+    opt_h.load_state_dict(ck["optimizer_state_dict"])
+    assert opt_h.step_count == 2 and float(opt_h.exp_avg.abs().sum()) > 0
+    for p, g in zip(ref.parameters(), grads[2]):
+        p.grad = g.clone()
+    opt_r.step()
+    opt_h.zero_grad()
+    for p, g in zip(hip.parameters(), grads[2]):
+        p.grad.copy_(g.to(dev))
+    opt_h.step()
+    for (n, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()):
+        close(p, q, rtol=1e-5, atol=1e-7, what=n)
+    # (2) back into torch
+    torch.save({"optimizer_state_dict": opt_h.state_dict()}, tmp_path / "ck2.pth")
+    sd = torch.load(tmp_path / "ck2.pth", map_location="cpu", weights_only=True)["optimizer_state_dict"]
+    assert set(sd["state"].keys()) == set(range(len(list(ref.parameters())))) and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ref2 = seed_module_(oref.TrajectoryPolicy(10, 256), 61)
+    opt_r2 = torch.optim.AdamW(ref2.parameters(), lr=1e-3, weight_decay=1e-2)
+    opt_r2.load_state_dict(sd)
+    for (k, st), (_, st_r) in zip(sorted(opt_r2.state_dict()["state"].items()), sorted(opt_r.state_dict()["state"].items())):
+        assert float(st["step"]) == float(st_r["step"]) == 3.0
+        close(st["exp_avg"], st_r["exp_avg"], rtol=1e-5, atol=1e-9, what=f"exp_avg[{k}]")
+        close(st["exp_avg_sq"], st_r["exp_avg_sq"], rtol=1e-5, atol=1e-12, what=f"exp_avg_sq[{k}]")
+    # (3) NuScenes checkpoint with the older key names
+    ref4 = seed_module_(oref.create_automoe_model(FOUR_EXPERT_CFG, "cpu"), 124)
+    fresh = create_automoe_model(FOUR_EXPERT_CFG, dev)
+    paths = []
+    for i, e in enumerate(ref4.experts):
+        sd_e = e.state_dict()
+        if i == 3:
+            sd_e = {("mlp." + k[len("decoder."):] if k.startswith("decoder.") else
+                     "box_head." + k[len("bbox_head."):] if k.startswith("bbox_head.") else k): v for k, v in sd_e.items()}
+            assert any(k.startswith("mlp.") for k in sd_e) and any(k.startswith("box_head.") for k in sd_e)
+        torch.save({"epoch": 1, "model_state_dict": sd_e}, tmp_path / f"e{i}.pth")
+        paths.append(str(tmp_path / f"e{i}.pth"))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a failed load is only a warning in the reference API: make it fail the test
+        fresh.load_expert_checkpoints(paths)
+    for (n, a), (_, b) in zip(fresh.experts.state_dict().items(), ref4.experts.state_dict().items()):
+        assert torch.equal(a.cpu(), b), n

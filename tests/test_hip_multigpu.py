@@ -1,0 +1,190 @@
+"""GPU tests of the data-parallel path (reference: torch DDP at training/train_bdd100k_ddp.py:497,
+training/train_gating_network.py:220-236, launcher line training/train_gating_network.sh:111).
+
+The test box has ONE GPU and RCCL refuses two ranks on one device, so:
+  * two-rank cases run over gloo with both ranks on the shared GPU (the bucket / notification / agreement logic is the
+    backend-independent part);
+  * RCCL itself, and the capture of the bucket collectives into the step's hipGraph, run on a one-rank "nccl" group
+    (the collective launches, the side-stream fork / join and c10d's capture handling are exactly those of N ranks).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(script_path, nproc, port, args, timeout=900, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script_path)] + [str(a) for a in args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+_GRAD_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+from _seeded import seed_module_, seeded_tensor
+from oracle import torch_ref as oref
+from oracle.losses import gating_losses
+from self_driving_model_amd import runtime
+from self_driving_model_amd.models.automoe import create_automoe_model
+from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="env://")
+cfg = {"experts": [{"type": "detection", "pretrained_backbone": False}, {"type": "drivable", "pretrained_backbone": False}],
+       "gating": {"processed_dim": 256, "hidden_dim": 128}, "context": {"type": "simple", "context_dim": 64}, "policy": {"num_waypoints": 10}}
+# the mean of per-rank gradients is the global-batch gradient only where nothing couples samples across the batch:
+# BatchNorm in eval mode (torch DDP keeps per-rank batch statistics too) and no load-balancing term (a function of the batch-mean gate)
+tcfg = {"learning_rate": 1e-3, "weight_decay": 1e-4, "use_load_balancing": False}
+ref = seed_module_(oref.create_automoe_model(cfg, "cpu"), 7)
+runtime.set_compute_dtype(torch.float32)
+m = create_automoe_model(cfg, "cpu"); m.load_state_dict(ref.state_dict()); m.to("cuda:0")
+for mod in (m, ref):
+    mod.freeze_experts(); mod.eval()
+    for d in mod.modules():
+        if isinstance(d, torch.nn.Dropout): d.p = 0.0
+os.environ["AUTOMOE_BUCKET_MB"] = "1"   # several buckets even for the 11.5 MB of the frozen-expert stage
+step = GatingTrainStep(m, tcfg, use_graph=False)
+assert step.reducer.enabled and len(step.reducer.buckets) >= 4, len(step.reducer.buckets)
+B = 2
+def shard(r):
+    return {"image": seeded_tensor((B, 3, 64, 96), 100 + r), "speed": seeded_tensor((B, 10), 110 + r), "steering": seeded_tensor((B, 10), 120 + r),
+            "throttle": seeded_tensor((B, 10), 130 + r), "brake": seeded_tensor((B, 10), 140 + r), "waypoints": seeded_tensor((B, 10, 2), 150 + r)}
+batch = {k: v.to("cuda:0") for k, v in shard(rank).items()}
+step._fwd_bwd(batch)
+step.reducer.finish()
+torch.cuda.synchronize()
+g = (step.optimizer.flat_g / world).cpu()
+if rank == 0:
+    glob = {k: torch.cat([shard(r)[k] for r in range(world)]) for k in shard(0)}
+    gating_losses(ref(glob), glob["waypoints"], glob["speed"], tcfg)["total_loss"].backward()
+    worst = 0.0
+    names = dict(m.named_parameters())
+    for (n, q) in ref.named_parameters():
+        if not q.requires_grad or q.grad is None:
+            continue
+        i = [j for j, p in enumerate(step.optimizer._params) if p is names[n]][0]
+        o = step.optimizer._offsets[i]
+        gh = g[o:o + q.numel()].view(q.shape)
+        err = (gh - q.grad).abs() - (1e-5 + 1e-3 * q.grad.abs())
+        worst = max(worst, float(err.max()))
+        assert float(err.max()) <= 0, (n, float((gh - q.grad).abs().max()), float(q.grad.abs().max()))
+    print("grad-ok worst margin", worst)
+dist.barrier(); dist.destroy_process_group()
+print("rank-done", rank)
+'''
+
+
+def test_two_rank_reduced_gradient_equals_oracle_global_batch_gradient(tmp_path):
+    """What DDP promises (train_gating_network.py:236): after the exchange every rank holds the gradient of the GLOBAL
+    batch.  Two ranks (different shards) run forward + backward + the bucketed all-reduce (1 MB buckets, direct-mode
+    parameter gradients reporting through runtime.grad_ready); the reduced flat gradient / world is compared with the
+    oracle's gradient on the concatenated batch at the north_star tolerance, rtol 1e-3 / atol 1e-5, fp32 mode."""
+    script = tmp_path / "grad_worker.py"
+    script.write_text(_GRAD_WORKER)
+    r = _run_ranks(script, 2, 29671, [ROOT])
+    assert "grad-ok" in r.stdout and r.stdout.count("rank-done") == 2, r.stdout[-2000:]
+
+
+def test_bench_gpus2_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) is the driver's scaling command: it must start two ranks
+    as child processes and print ONE JSON line with n_gpus == 2.  gloo transport: both ranks share the box's one GPU."""
+    env = dict(os.environ, AUTOMOE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "3", "--batch", "4",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["hipgraph"] is True
+
+
+_NCCL1_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+from _seeded import seed_module_, seeded_tensor
+from oracle import torch_ref as oref
+from self_driving_model_amd import runtime
+from self_driving_model_amd.models.automoe import create_automoe_model
+from self_driving_model_amd.models.experts import BDDDrivableExpert
+from self_driving_model_amd.training import synthetic
+from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="env://")   # RCCL, one rank
+cfg = {"experts": [{"type": "detection", "pretrained_backbone": False}, {"type": "drivable", "pretrained_backbone": False}],
+       "gating": {"processed_dim": 256, "hidden_dim": 128}, "context": {"type": "simple", "context_dim": 64}, "policy": {"num_waypoints": 10}}
+ref = seed_module_(oref.create_automoe_model(cfg, "cpu"), 7)
+runtime.set_compute_dtype(torch.float32)
+os.environ["AUTOMOE_BUCKET_MB"] = "1"
+B = 2
+batch = {k: v.to("cuda:0") for k, v in {"image": seeded_tensor((B, 3, 64, 96), 100), "speed": seeded_tensor((B, 10), 110),
+         "steering": seeded_tensor((B, 10), 120), "throttle": seeded_tensor((B, 10), 130), "brake": seeded_tensor((B, 10), 140),
+         "waypoints": seeded_tensor((B, 10, 2), 150)}.items()}
+odd = {k: v[:1].contiguous() for k, v in batch.items()}
+res = {}
+for forced in (False, True):
+    os.environ["AUTOMOE_DDP_FORCE"] = "1" if forced else "0"
+    m = create_automoe_model(cfg, "cpu"); m.load_state_dict(ref.state_dict()); m.to("cuda:0"); m.freeze_experts(); m.train()
+    for d in m.modules():
+        if isinstance(d, torch.nn.Dropout): d.p = 0.0
+    step = GatingTrainStep(m, {"learning_rate": 1e-3, "weight_decay": 1e-4}, use_graph=True)
+    assert step.reducer.enabled == forced
+    losses = [float(step(odd if i == 4 else batch, next_batch=(batch if i != 3 else odd))["total_loss"]) for i in range(7)]
+    assert step._graph is not None
+    if forced:
+        assert step.reducer.capturable and step._reduce_in_graph, "bucket collectives were not captured with the step"
+        assert len(step.reducer.buckets) >= 4
+    res[forced] = (losses, step.optimizer.flat_p.detach().cpu().clone())
+torch.testing.assert_close(torch.tensor(res[True][0]), torch.tensor(res[False][0]), rtol=2e-3, atol=1e-4)
+torch.testing.assert_close(res[True][1], res[False][1], rtol=5e-3, atol=5e-4)
+print("gating-capture-ok", res[True][0][0], res[True][0][-1])
+
+# trainable expert (49 MB of gradients in 4 MB buckets): the collectives sit between the backward kernels of the graph
+os.environ["AUTOMOE_BUCKET_MB"] = "4"
+fin = {}
+for forced in (False, True):
+    os.environ["AUTOMOE_DDP_FORCE"] = "1" if forced else "0"
+    torch.manual_seed(11)
+    e = BDDDrivableExpert(3, pretrained_backbone=False).to("cuda:0").train()
+    b = synthetic.bdd_drivable_batch(2, 128, 160, 3, torch.device("cuda:0"), seed=3)
+    loader = synthetic.SyntheticLoader(b, 8)
+    tr = BDDTrainer("drivable", e, loader, loader, torch.device("cuda:0"), {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1,
+                                                                            "run_name": "t", "use_graph": True})
+    ls = [float(tr.train_step(b)) for _ in range(6)]
+    assert tr._graph is not None and tr._reduce_in_graph == forced
+    if forced:
+        assert len(tr.reducer.buckets) >= 8
+    fin[forced] = ls
+torch.testing.assert_close(torch.tensor(fin[True]), torch.tensor(fin[False]), rtol=5e-3, atol=1e-4)
+print("expert-capture-ok", fin[True][0], fin[True][-1])
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_bucket_allreduce_captured_in_step_graph(tmp_path):
+    """RCCL ("nccl" backend) on a one-rank group: the per-bucket all-reduces are recorded INTO the step's hipGraph (event on
+    the compute stream, collective on the side stream, join before the optimizer) for the gating step (direct-mode gradient
+    notifications, expert prefetch, a ragged batch in between) and for a trainable expert; with one rank the sum is the
+    identity, so the trajectory must be the one of the step without any reducer."""
+    script = tmp_path / "nccl1_worker.py"
+    script.write_text(_NCCL1_WORKER)
+    r = _run_ranks(script, 1, 29673, [ROOT])
+    assert "gating-capture-ok" in r.stdout and "expert-capture-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
