@@ -104,10 +104,26 @@ int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* 
 int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
                        const void* w, void* y, double* stats, am_stream_t stream);
 
-/* Diagnostic (bench.py roofline leg): which kernel the last am_conv_gemm / am_conv_first_fused call of this process launched.
+/* Diagnostic (bench.py roofline leg, kernel tests): which kernel the last am_conv_gemm / am_conv_first_fused / am_conv_wgrad call
+ * made by the CALLING HOST THREAD launched (thread-local record).
  * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 conv3x3_c64n64_wreg_k,
- * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k. */
+ * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
+ * 11 conv_ring16_k<256,256>, 12 conv_ring16_k<256,128>, 13 wgrad_ring_k, 14 conv_wgrad_k (register-staged), 15 conv_s2d_wgrad_k. */
 int am_conv_last_variant(void);
+
+/* Process-wide A/B switches between kernels that compute the same result (diagnostic / tuning use: tests pin a kernel, bench
+ * compares two).  The only mutable state the library keeps besides the per-thread am_conv_last_variant() record.  Set before
+ * launching; returns the previous value (AM_ERR_ARG for an unknown key).
+ *   AM_TUNE_RING   0: conv_ring_k (v_mfma_f32_32x32x16_f16), 1: conv_ring16_k (16x16x32, transposed product, pieces issued as a
+ *                  block), 2: conv_ring16_k with the LDS-DMA pieces spread between the MFMA groups.
+ *   AM_TUNE_RING128_MIN_TILES   fewest 256x128 tiles (M/256 * N/128) for which conv_ring_k<256,128> is dispatched.
+ *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k. */
+#define AM_TUNE_RING 0
+#define AM_TUNE_RING128_MIN_TILES 1
+#define AM_TUNE_WGRAD_RING 2
+#define AM_TUNE_COUNT 3
+int am_set_tuning(int key, int value);
+int am_get_tuning(int key);
 
 /* Diagnostic (bench.py roofline leg): what workgroup 0 of the last conv_ring_k<256,256> launch measured inside its K-loop --
  * out[0] shader-clock cycles (s_memtime), out[1] ticks of the constant 100 MHz clock (s_memrealtime), out[2] K-steps (the
@@ -121,6 +137,16 @@ int am_diag_ring_clock(long long* out, am_stream_t stream);
  * geometry's OUTPUT pixels (pixel stride ldo, channel y_coff).  `scale` undoes loss scaling. */
 int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale,
                   float* dw, am_stream_t stream);
+/* Workspace form of am_conv_wgrad (the caller owns scratch memory, sized by a query): every pixel chunk of the split
+ * contraction stores its partial dW tile with plain stores into its own slab of `workspace`; a second pass sums the slabs and
+ * writes dw_oihw[n][c][t] (the nn.Conv2d weight layout, c < cin, t = kh*KW + kw), = or += by `accumulate` -- no device-scope fp32
+ * atomics (they bound the atomic form at ~1.3 TB/s of added bytes), no zero-filled staging tensor, no re-layout pass, and a
+ * bitwise reproducible sum.  am_conv_wgrad_workspace_bytes() gives the size for a geometry (0: that geometry runs a kernel
+ * without a slab form -- the 3-channel first layers -- and am_conv_wgrad_ws returns AM_ERR_UNSUPPORTED: use am_conv_wgrad).
+ * `workspace` must be 16-byte aligned; it needs no initialisation. */
+int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, long long* bytes);
+int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale, void* workspace,
+                     long long workspace_bytes, float* dw_oihw, int cin, int accumulate, am_stream_t stream);
 /* am_bn_bwd_apply + am_conv_wgrad in one launch for a layer whose input needs no gradient (the 3-channel first layers:
  * trajectory_head.py:10-12 conv -> BN -> ReLU on the image): `dy` is the gradient w.r.t. the BN(+ReLU) output, `raw` the conv
  * output, `yout` the BN+ReLU output (ReLU mask; NULL without ReLU), mean/rstd the saved batch statistics, coef = [3][N] from
@@ -290,8 +316,10 @@ int am_lsap_batched(const float* cost, int B, int nr, const int32_t* nc_per, int
  * (torch.optim.AdamW arithmetic), non-finite norm => step skipped and counted.
  * ------------------------------------------------------------------------------------------ */
 int am_sumsq_accumulate(const float* x, long long n, double* acc, am_stream_t stream);
-int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
+/* hyper-parameters as doubles: torch.optim.AdamW derives 1 - beta, lr / (1 - beta1^t), 1 - lr*wd in double and rounds each to
+ * fp32 once; doing the same keeps the moments interchangeable with a torch optimizer's state (checkpoint resume both ways). */
+int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
                   am_stream_t stream);
 int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_stream_t stream);
 

@@ -54,10 +54,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 static inline int am_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// Diagnostic only (bench.py's roofline leg attributes launch times to kernels): id of the conv kernel the last am_conv_gemm /
-// am_conv_first_fused call on this process launched.  Not synchronised across host threads.
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: launchers keep one "done" flag per device
+// (a benign race: two threads may both set the same value).
+constexpr int AM_MAX_DEVICES = 64;
+static inline int am_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= AM_MAX_DEVICES) d = 0;
+  return d;
+}
+
+// Diagnostic only (bench.py's roofline leg and the tests attribute launches to kernels): id of the conv kernel the last
+// am_conv_gemm / am_conv_first_fused / am_conv_wgrad call MADE BY THIS HOST THREAD launched (thread-local: no shared mutable state).
 enum am_conv_variant_id {
   AM_CV_NONE = 0, AM_CV_RING_256x256, AM_CV_RING_256x128, AM_CV_DUO_C64, AM_CV_WREG_C64, AM_CV_PATCH_C64, AM_CV_LDSDMA_V2,
-  AM_CV_LDSDMA_RING_V1, AM_CV_REGSTAGED, AM_CV_S2D, AM_CV_S2D_POOL
+  AM_CV_LDSDMA_RING_V1, AM_CV_REGSTAGED, AM_CV_S2D, AM_CV_S2D_POOL, AM_CV_RING16_256x256, AM_CV_RING16_256x128,
+  AM_CV_WGRAD_RING, AM_CV_WGRAD_REGSTAGED, AM_CV_WGRAD_S2D
 };
-extern int g_am_conv_variant;
+extern thread_local int g_am_conv_variant;
+
+// Process-wide tuning switches (am_set_tuning, include/automoe_hip.h): A/B selection between kernels that compute the same
+// thing.  Read with am_tuning(key); set once before launching (plain ints: not meant to be flipped concurrently with launches).
+int am_tuning(int key);

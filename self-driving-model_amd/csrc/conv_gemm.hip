@@ -324,7 +324,8 @@ int launch_conv_m(const ConvKParams& p, hipStream_t s) {
   q.mtiles = am_cdiv(p.M, BM);
   q.ntiles = am_cdiv(p.g.N, BN);
   const size_t lds = (2 * STAGE > EPI ? 2 * STAGE : EPI) + BM * sizeof(int);
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (lds > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_k<T, BM, BN, WM, WN, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;
@@ -378,6 +379,8 @@ struct WgradParams {
   const void* x;
   const void* dy;
   float* dw;
+  float* ws;            // slab mode (am_conv_wgrad_ws): chunk c stores its unscaled partial tile at ws + c * ws_stride
+  long long ws_stride;
   float scale;
   int M, nk, ksteps_per_tap, Ktot, ktiles, ntiles, mchunks, mc;
 };
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
     }
   }
 
-  // flush: fp32 atomics, rows = output channel n, cols = packed k
+  // flush, rows = output channel n, cols = packed k: plain stores into this pixel chunk's slab (slab mode) or fp32 atomics
+  float* slab = p.ws ? p.ws + (size_t)mcid * p.ws_stride : nullptr;
 #pragma unroll
   for (int tn = 0; tn < TNK; ++tn) {
     const int kc = kk0 * BK + (wk * TNK + tn) * 32 + (lane & 31);
@@ -526,13 +530,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + (wn * TMN + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N) atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+        if (n < g.N) {
+          if (slab) slab[(size_t)n * p.Ktot + kc] = acc[tm][tn][r];
+          else atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+        }
       }
   }
 }
 
+// Second pass of am_conv_wgrad_ws: out = (accumulate ? out : 0) + scale * sum over the pixel chunks' slabs, written in the
+// nn.Conv2d weight layout out[n][c][t] (OIHW: t = kh * KW + kw) from the packed k = t * krun + c.  A thread owns one packed
+// element: slab reads are coalesced along k; the scattered 4-byte writes touch a few MB at most.
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int N, int Ktot, int krun,
+                                                      int cin, int ntaps, float scale, float* __restrict__ out, int accumulate) {
+  const long long total = (long long)N * Ktot;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / Ktot), k = (int)(i - (long long)n * Ktot);
+    const int t = k / krun, c = k - t * krun;
+    if (c >= cin) continue;
+    float sum = 0.f;
+    for (int s = 0; s < nchunks; ++s) sum += ws[(size_t)s * ws_stride + i];
+    float* o = out + ((size_t)n * cin + c) * ntaps + t;
+    *o = accumulate ? *o + sum * scale : sum * scale;
+  }
+}
+
 template <typename T, int BNO, int NS>
-int launch_wgrad(const WgradParams& p0, hipStream_t s) {
+int launch_wgrad(const WgradParams& p0, hipStream_t s, bool plan_only = false) {
   constexpr int PS = sizeof(T) == 2 ? 64 : 32;
   constexpr int PDY = BNO * (int)sizeof(T) + 64, PX = NS * 64 + 64;
   WgradParams p = p0;
@@ -546,7 +570,9 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
   mc = am_cdiv(mc, PS * 4) * PS * 4;  // at least 4 steps per chunk
   p.mc = mc;
   p.mchunks = am_cdiv(p.M, mc);
+  if (plan_only) return p.mchunks;
   const size_t lds = (size_t)PS * (PDY + PX);
+  g_am_conv_variant = AM_CV_WGRAD_REGSTAGED;
   hipLaunchKernelGGL((conv_wgrad_k<T, BNO, NS>), dim3(tiles * p.mchunks), dim3(256), lds, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
@@ -554,7 +580,8 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s) {
 
 }  // namespace
 
-int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s);  // conv_wgrad_ring.hip
+int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
+                           bool plan_only, hipStream_t s);  // conv_wgrad_ring.hip
 int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
                           const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
@@ -574,9 +601,26 @@ static bool use_v1_only() {
   return v == 1;
 }
 
-int g_am_conv_variant = AM_CV_NONE;
+thread_local int g_am_conv_variant = AM_CV_NONE;
 
 extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
+
+static int g_tuning[AM_TUNE_COUNT] = {
+    /* AM_TUNE_RING */ 1,
+    /* AM_TUNE_RING128_MIN_TILES */ 192,
+    /* AM_TUNE_WGRAD_RING */ 1,
+};
+
+int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }
+
+extern "C" int am_set_tuning(int key, int value) {
+  if (key < 0 || key >= AM_TUNE_COUNT) return AM_ERR_ARG;
+  const int old = g_tuning[key];
+  g_tuning[key] = value;
+  return old;
+}
+
+extern "C" int am_get_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : AM_ERR_ARG; }
 
 int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                      hipStream_t s);  // conv_ring.hip
@@ -633,6 +677,35 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   return dtype == AM_F16 ? dispatch_conv<half_t>(p, s) : dispatch_conv<float>(p, s);
 }
 
+// Shared dispatcher of am_conv_wgrad (atomic form: ws == nullptr) and am_conv_wgrad_ws (slab form).  plan_only: launches nothing,
+// returns the number of pixel chunks (= slabs) of the kernel that would run, 0 when that kernel has no slab form.
+static int wgrad_dispatch(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale, float* dw, float* ws,
+                          long long ws_stride, bool plan_only, hipStream_t s) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  WgradParams p;
+  p.g = *g;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale; p.ws = ws; p.ws_stride = ws_stride;
+  p.M = g->B * g->MH * g->MW;
+  p.ksteps_per_tap = g->krun * es / 64;
+  p.nk = g->ntaps * p.ksteps_per_tap;
+  p.Ktot = g->ntaps * g->krun;
+  p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
+  if (dtype == AM_F16) {
+    static int s2dw = -1;
+    if (s2dw < 0) { const char* e = getenv("AM_WGRAD_S2D"); s2dw = e ? atoi(e) : 1; }
+    if (s2dw && g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip); atomic form only
+      if (plan_only || ws) return plan_only ? 0 : AM_ERR_UNSUPPORTED;
+      const int rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
+      if (rc != AM_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, ws, ws_stride, plan_only, s);  // LDS-DMA ring kernel: N % 128 == 0, long contractions
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+    if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s, plan_only);
+    return launch_wgrad<half_t, 64, 4>(p, s, plan_only);
+  }
+  return launch_wgrad<float, 64, 4>(p, s, plan_only);
+}
+
 extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale,
                              float* dw, am_stream_t stream) {
   int rc = check_geom(g, dtype);
@@ -640,29 +713,45 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
   if (!x || !dy || !dw || g->ntaps <= 0) return AM_ERR_ARG;
   const int es = dtype == AM_F16 ? 2 : 4;
   if ((g->ldo * es) % 16 != 0 || (g->y_coff * es) % 16 != 0) return AM_ERR_ARG;
-  WgradParams p;
-  p.g = *g;
-  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
-  p.M = g->B * g->MH * g->MW;
-  if (p.M == 0) return AM_OK;
-  p.ksteps_per_tap = g->krun * es / 64;
-  p.nk = g->ntaps * p.ksteps_per_tap;
-  p.Ktot = g->ntaps * g->krun;
-  p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
+  return wgrad_dispatch(g, dtype, x, dy, scale, dw, nullptr, 0, false, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, long long* bytes) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!bytes || g->ntaps <= 0) return AM_ERR_ARG;
+  *bytes = 0;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
+  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
+  if (chunks < 0) return chunks;
+  *bytes = (long long)chunks * g->N * g->ntaps * g->krun * 4;
+  return AM_OK;
+}
+
+extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale, void* workspace,
+                                long long workspace_bytes, float* dw_oihw, int cin, int accumulate, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !dy || !dw_oihw || g->ntaps <= 0 || cin <= 0 || cin > g->krun) return AM_ERR_ARG;
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if ((g->ldo * es) % 16 != 0 || (g->y_coff * es) % 16 != 0) return AM_ERR_ARG;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == AM_F16) {
-    static int s2dw = -1;
-    if (s2dw < 0) { const char* e = getenv("AM_WGRAD_S2D"); s2dw = e ? atoi(e) : 1; }
-    if (s2dw && g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip)
-      rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
-      if (rc != AM_ERR_UNSUPPORTED) return rc;
-    }
-    rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, s);  // LDS-DMA ring kernel (conv_wgrad_ring.hip): N % 128 == 0, long contractions
-    if (rc != AM_ERR_UNSUPPORTED) return rc;
-    if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s);
-    return launch_wgrad<half_t, 64, 4>(p, s);
-  }
-  return launch_wgrad<float, 64, 4>(p, s);
+  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
+  if (chunks < 0) return chunks;
+  if (chunks == 0) return AM_ERR_UNSUPPORTED;  // first-layer kernel: atomic form only (caller: am_conv_wgrad + its own unpack)
+  const long long Ktot = (long long)g->ntaps * g->krun, stride = (long long)g->N * Ktot;
+  if (!workspace || workspace_bytes < chunks * stride * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return AM_ERR_ARG;
+  rc = wgrad_dispatch(g, dtype, x, dy, 1.f, nullptr, static_cast<float*>(workspace), stride, false, s);
+  if (rc != AM_OK) return rc;
+  const long long total = stride;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((int)blocks), dim3(256), 0, s, static_cast<const float*>(workspace), chunks, stride, g->N, (int)Ktot,
+                     g->krun, cin, g->ntaps, scale, dw_oihw, accumulate);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
 }
 
 int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,

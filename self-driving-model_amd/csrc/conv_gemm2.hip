@@ -502,7 +502,8 @@ int launch3(const Conv2Params& p0, hipStream_t s) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr size_t EPI = 8192 + (size_t)WM * WN * (TM * 32) * (TN * 64 + 16);
   const size_t lds = 3 * STAGE > EPI ? 3 * STAGE : EPI;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (lds > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm3_k<BM, BN, WM, WN, BKB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;
@@ -525,7 +526,8 @@ int launch2(const Conv2Params& p0, hipStream_t s) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr size_t EPI = 8192 + 4 * (size_t)(TM * 32) * (TN * 64 + 16);  // staged epilogue (reuses the stage buffers)
   const size_t lds = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (lds > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm2_k<BM, BN, WM, WN, BKB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;

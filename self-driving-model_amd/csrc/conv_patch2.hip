@@ -266,7 +266,8 @@ int am_conv3x3_c64n64_wreg_f16(const am_conv_geom* g, const void* x, const void*
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
   p.x_bytes = (unsigned)x_bytes;
   { const char* e = getenv("AM_PATCH_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64n64_wreg_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return AM_ERR_LAUNCH;

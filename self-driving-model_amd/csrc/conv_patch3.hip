@@ -354,7 +354,8 @@ int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const fl
   p.w_bytes = 64 * WROW;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.y_bytes = (unsigned)y_bytes;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64n64_duo_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return AM_ERR_LAUNCH;

@@ -326,7 +326,8 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr size_t EPI = 8192 + (size_t)WM * WN * (TM * 32) * (TN * 64 + 16);
   const size_t lds = 3 * STAGE > EPI ? 3 * STAGE : EPI;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (lds > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ring_k<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AM_ERR_LAUNCH;
@@ -342,9 +343,18 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
 
 // Called by am_conv_gemm2_f16 (conv_gemm2.hip); returns AM_ERR_UNSUPPORTED when the shape is not covered.
 // `npad_rows` = rows of the packed weight matrix (am_conv_npad).
+int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+                       int variant, int* tile_out, hipStream_t s);  // conv_ring16.hip
+
 int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                      hipStream_t s) {
   using namespace amr;
+  if (const int t = am_tuning(AM_TUNE_RING); t > 0) {  // 16x16x32 generation (conv_ring16.hip): the 256x256 tile
+    int tile = 0;
+    const int rc = am_conv_ring16_f16(g, x, w, bias, relu, y, stats, t - 1, &tile, s);
+    if (rc == AM_OK) g_am_conv_variant = tile == 1 ? AM_CV_RING16_256x256 : AM_CV_RING16_256x128;
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+  }
   if (g->ntaps <= 0 || g->ntaps > RING_MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0 || g->N <= 64) return AM_ERR_UNSUPPORTED;
   const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
   const long long Ktot = (long long)g->ntaps * g->krun;
@@ -367,14 +377,19 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) return launch_ring<256, 256, 2, 4>(p, s);
   static int n128 = -1;
   if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
-  if (mt256 * ((g->N + 127) / 128) >= 256) return n128 == 1 ? launch_ring<256, 128, 2, 2>(p, s) : launch_ring<256, 128, 4, 2>(p, s);
+  // 256x128 tiles run two workgroups per CU (72 KiB of LDS each); below one workgroup per CU a lone workgroup still has its CU's
+  // matrix pipes to itself, so the ring kernel keeps beating the two-stage kernels down to AM_TUNE_RING128_MIN_TILES tiles
+  if (mt256 * ((g->N + 127) / 128) >= am_tuning(AM_TUNE_RING128_MIN_TILES)) return n128 == 1 ? launch_ring<256, 128, 2, 2>(p, s) : launch_ring<256, 128, 4, 2>(p, s);
   return AM_ERR_UNSUPPORTED;
 }
 
 // out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = K-steps of workgroup 0's K-loop in the last 256x256 ring launch
 // (synchronises the stream).  MFMA floor of that loop: 1024 cycles per K-step.
+int am_diag_ring16_clock(long long* out);  // conv_ring16.hip
+
 extern "C" int am_diag_ring_clock(long long* out, void* stream) {
   if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return AM_ERR_LAUNCH;
+  if (am_tuning(AM_TUNE_RING) > 0) return am_diag_ring16_clock(out);
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(amr::g_ring_clk), 3 * sizeof(long long)) != hipSuccess) return AM_ERR_LAUNCH;
   return AM_OK;
 }

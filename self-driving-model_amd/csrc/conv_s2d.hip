@@ -322,7 +322,8 @@ int launch_s2d(const S2dParams& p, hipStream_t s) {
   constexpr int W_BYTES = ((NCH * WPITCH + 1023) / 1024) * 1024;
   constexpr int STG = 4 * 32 * (NCH * 2 + 16);
   constexpr int LDS = W_BYTES + 2 * PATCH_SLOT + (STG > 4 * NCH * 8 ? STG : 4 * NCH * 8);
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (LDS > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_k<TAPS, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
@@ -603,7 +604,8 @@ int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
   S2dParams p = p0;
   const int pty = am_cdiv(POH, PTH), ptx = am_cdiv(POW, PTW);
   p.ntiles = p.B * pty * ptx;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_pool_k<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;

@@ -202,13 +202,15 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int DYS = TH * TW * (NT == 1 ? 64 : 192);
   constexpr int RED = NT * 32 * TAPS * 64 * 4;
   constexpr int LDS = (PATCH + DYS) > RED ? (PATCH + DYS) : RED;
-  static bool attr_done = false;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (LDS > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_wgrad_k<TAPS, NT, BNF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   const int grid = p.ntiles < 512 ? p.ntiles : 512;  // persistent: two workgroups per CU
+  g_am_conv_variant = AM_CV_WGRAD_S2D;
   hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT, BNF>), dim3(grid), dim3(256), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;

@@ -30,6 +30,8 @@ struct WrParams {
   const void* x;
   const void* dy;
   float* dw;
+  float* ws;             // slab mode: chunk c stores its unscaled partial tile at ws + c * ws_stride (plain stores, no atomics)
+  long long ws_stride;   // elements between two chunks' slabs (>= rows * Ktot)
   float scale;
   int M, Ktot, kpt, nslab, ktiles, ntiles, mchunks, mc;
   unsigned x_bytes, dy_bytes;
@@ -199,7 +201,10 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- flush: fp32 atomics; a lane owns k-column (lane & 31) of its 32-block: 128 contiguous bytes per register and row ----
+  // ---- flush; a lane owns k-column (lane & 31) of its 32-block: 128 contiguous bytes per register and row.  Slab mode: plain
+  // stores of the unscaled partial tile into this pixel chunk's slab (am_conv_wgrad_ws sums the slabs in a second pass: no
+  // device-scope atomics, which run at ~1.3 TB/s of added bytes chip-wide and cost this kernel ~30 %); else fp32 atomics ----
+  float* part = p.ws ? p.ws + (size_t)mcid * p.ws_stride : nullptr;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int kc = kt * 256 + (wn * TN + tn) * 32 + (lane & 31);
@@ -209,13 +214,16 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N) atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+        if (n < g.N) {
+          if (part) part[(size_t)n * p.Ktot + kc] = acc[tm][tn][r];
+          else atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+        }
       }
   }
 }
 
 template <int TM>
-int launch(const WrParams& p0, hipStream_t s) {
+int launch(const WrParams& p0, hipStream_t s, bool plan_only) {
   constexpr int BNT = 2 * TM * 32;
   constexpr int NI_A = PS / (1024 / (BNT * 2));
   constexpr int LDS = 3 * (NI_A + NI_X) * PIECE;
@@ -233,12 +241,15 @@ int launch(const WrParams& p0, hipStream_t s) {
   mc = am_cdiv(mc, PS * 8) * PS * 8;  // at least 8 steps per chunk, whole steps
   p.mc = mc;
   p.mchunks = am_cdiv(p.M, mc);
-  static bool attr_done = false;
+  if (plan_only) return p.mchunks;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_k<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
+  g_am_conv_variant = AM_CV_WGRAD_RING;
   hipLaunchKernelGGL((wgrad_ring_k<TM>), dim3(tiles * p.mchunks), dim3(512), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
@@ -246,12 +257,13 @@ int launch(const WrParams& p0, hipStream_t s) {
 
 }  // namespace awr
 
-// Called by am_conv_wgrad (conv_gemm.hip) for f16 problems; AM_ERR_UNSUPPORTED when the shape is not covered.
-int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, hipStream_t s) {
+// Called by am_conv_wgrad / am_conv_wgrad_ws (conv_gemm.hip) for f16 problems; AM_ERR_UNSUPPORTED when the shape is not covered.
+// ws != nullptr: slab mode (ws_stride elements per pixel chunk).  plan_only: launches nothing and returns the number of pixel
+// chunks (> 0) the launch would use.
+int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
+                           bool plan_only, hipStream_t s) {
   using namespace awr;
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("AM_WGRAD_RING"); on = e ? atoi(e) : 1; }
-  if (!on) return AM_ERR_UNSUPPORTED;
+  if (!am_tuning(AM_TUNE_WGRAD_RING)) return AM_ERR_UNSUPPORTED;
   if (g->ntaps <= 0 || g->pix_shift != 31 || (g->krun * 2) % 64 != 0) return AM_ERR_UNSUPPORTED;
   if (g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0 || g->MH != g->OH || g->MW != g->OW) return AM_ERR_UNSUPPORTED;  // GEMM row == output pixel
   if (g->MW < PS || (g->N % 128) != 0 || (g->y_coff * 2) % 16 != 0 || (g->ldo * 2) % 16 != 0 || (g->x_coff * 2) % 16 != 0) return AM_ERR_UNSUPPORTED;
@@ -262,7 +274,7 @@ int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy,
   if (x_bytes >= (1ll << 31) || dy_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
   WrParams p;
   p.g = *g;
-  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale; p.ws = ws; p.ws_stride = ws_stride;
   p.M = (int)M;
   p.Ktot = g->ntaps * g->krun;
   p.kpt = g->krun * 2 / 64;
@@ -272,6 +284,6 @@ int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy,
   p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
   for (int t = 0; t < AM_MAX_TAPS; ++t)
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
-  if (g->N % 256 == 0) return launch<4>(p, s);
-  return launch<2>(p, s);
+  if (g->N % 256 == 0) return launch<4>(p, s, plan_only);
+  return launch<2>(p, s, plan_only);
 }

@@ -26,9 +26,13 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, long
 // p, g, m, v: flat fp32 [n].  norm_sq: device scalar (sum of squares of ALL grads of the step, may
 // span several flat buffers).  clip_coef = min(1, max_norm / (sqrt(norm_sq) + 1e-6)) as torch's
 // clip_grad_norm_.  A non-finite norm skips the update (fp16 loss-scale overflow) and counts it.
+// Scalars arrive as torch applies them: computed in double on the host, rounded to fp32 once (decay = 1 - lr*wd, omb1 = 1 - beta1,
+// omb2 = 1 - beta2, step_size = lr / (1 - beta1^t), bias_c2_sqrt = sqrt(1 - beta2^t)); the moment updates are torch's own
+// expressions (exp_avg.lerp_(g, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(g, g, value = 1 - beta2)), so optimizer state
+// moves between this kernel and torch.optim.AdamW to the last bits.
 __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps,
-                                               float weight_decay, float bias_c1, float bias_c2_sqrt, float max_norm,
+                                               float* __restrict__ v, long long n, float decay, float omb1, float beta2, float omb2,
+                                               float eps, float step_size, float bias_c2_sqrt, float max_norm,
                                                const double* __restrict__ norm_sq, int* __restrict__ skipped) {
   float clip = 1.f;
   if (norm_sq) {
@@ -42,12 +46,11 @@ __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const floa
       clip = coef < 1.f ? coef : 1.f;
     }
   }
-  const float step_size = lr / bias_c1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * clip;
-    float pi = p[i] * (1.f - lr * weight_decay);
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    float pi = p[i] * decay;
+    const float mi = m[i] + omb1 * (gi - m[i]);
+    const float vi = beta2 * v[i] + omb2 * gi * gi;
     const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi;
@@ -91,15 +94,16 @@ extern "C" int am_sumsq_accumulate(const float* x, long long n, double* acc, am_
   return AM_OK;
 }
 
-extern "C" int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
+extern "C" int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
                              am_stream_t stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return AM_ERR_ARG;
   if (n == 0) return AM_OK;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)sqrt(bc2), max_norm, norm_sq, skipped);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n)), dim3(256), 0, ST(stream), p, g, m, v, n, (float)(1.0 - lr * weight_decay),
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), max_norm,
+                     norm_sq, skipped);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -359,6 +359,30 @@ def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None, k_real: Optio
                                                   ptr(y), ptr(stats), stream()))
 
 
+def conv_wgrad_oihw(g: ConvGeom, x, dy, scale: float, w_param, s: "ConvSpec"):
+    """Weight gradient in the nn.Conv2d layout through the workspace form (am_conv_wgrad_ws: per-chunk slabs + a summing pass,
+    no atomics, no staging tensor, no re-layout).  In direct mode (runtime.direct_grads) it is ADDED straight into
+    ``w_param.grad`` -- FusedAdamW's flat gradient buffer -- and None is returned (autograd has nothing to accumulate);
+    otherwise the fp32 OIHW gradient is returned.  NotImplemented when the geometry has no slab form (3-channel first layers)."""
+    import ctypes
+    L = _L()
+    code = dt_code(x.dtype)
+    nbytes = ctypes.c_longlong(0)
+    L.am_conv_wgrad_workspace_bytes(ctypes.byref(g), code, ctypes.byref(nbytes))
+    if nbytes.value <= 0 or s.first:
+        return NotImplemented
+    ws = torch.empty(nbytes.value // 4, dtype=torch.float32, device=x.device)
+    direct = _runtime().direct_grads() and _grad_ready(w_param) and tuple(w_param.shape) == (s.cout, s.cin, s.k, s.k)
+    out = w_param.grad if direct else torch.empty((s.cout, s.cin, s.k, s.k), dtype=torch.float32, device=x.device)
+    flops = 2.0 * g.B * g.MH * g.MW * s.cin * s.k * s.k * g.N
+    _timed("conv_wgrad", flops, lambda: L.am_conv_wgrad_ws(ctypes.byref(g), code, ptr(x), ptr(dy), float(scale), ptr(ws), nbytes.value,
+                                                           ptr(out), s.cin, int(direct), stream()))
+    if direct:
+        _runtime().grad_ready(w_param)
+        return None
+    return out
+
+
 def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp, k_real: Optional[int] = None):
     import ctypes
     flops = 2.0 * g.B * g.MH * g.MW * (k_real if k_real is not None else g.ntaps * g.krun) * g.N
@@ -367,6 +391,7 @@ def conv_wgrad(g: ConvGeom, x, dy, scale: float, dwp, k_real: Optional[int] = No
 
 
 PENDING_BN_COUNTERS = []
+USE_WGRAD_WORKSPACE = True  # tests flip this to compare the workspace form of the weight gradient with the atomic form
 FUSE_FIRST_LAYER = True  # tests flip this to compare the fused first layer with the unfused sequence
 
 
@@ -483,6 +508,7 @@ class ConvBnAct(torch.autograd.Function):
         ctx.cfg, ctx.geom = cfg, g
         ctx.has_res = residual is not None
         ctx.bn_params = (gamma, beta)
+        ctx.w_param = w  # the Parameter object itself (direct-mode weight gradients go into its .grad)
         ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if (cfg.relu or bn is None) else None, mean, rstd)
         return y
 
@@ -576,10 +602,12 @@ class ConvBnAct(torch.autograd.Function):
                     wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
                     conv_gemm(gd, dz, wd, None, False, dx, None, k_real=len(taps) * s.cout, kind="conv_dgrad")
         if ctx.needs_input_grad[1]:
-            ktot = g.ntaps * g.krun
-            dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
-            conv_wgrad(g, x, dz, inv, dwp, k_real=s.cin * s.k * s.k)
-            dw = unpack_wgrad(dwp, s, dtype)
+            dw = conv_wgrad_oihw(g, x, dz, inv, ctx.w_param, s) if USE_WGRAD_WORKSPACE else NotImplemented
+            if dw is NotImplemented:  # no slab form for this geometry: atomics into a packed staging tensor, then the re-layout
+                ktot = g.ntaps * g.krun
+                dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
+                conv_wgrad(g, x, dz, inv, dwp, k_real=s.cin * s.k * s.k)
+                dw = unpack_wgrad(dwp, s, dtype)
         return dx, dw, db, dgamma, dbeta, dres, None, None
 
 

@@ -20,6 +20,9 @@ AM_F32, AM_F16 = 0, 1
 AM_MAX_TAPS = 16
 AM_STATS_REPLICAS = 16
 AM_MAX_EXPERTS = 8
+AM_TUNE_RING = 0
+AM_TUNE_RING128_MIN_TILES = 1
+AM_TUNE_WGRAD_RING = 2
 
 _ERR = {-1: "AM_ERR_ARG (bad argument)", -2: "AM_ERR_LAUNCH (HIP runtime refused the launch)",
         -3: "AM_ERR_UNSUPPORTED (shape/dtype not built)"}
@@ -88,10 +91,15 @@ class _Lib:
             fn.restype = ctypes.c_int
             fn.argtypes = [t for _, t in args]
             setattr(self, "_raw_" + name, fn)
-            if name in ("am_version", "am_conv_npad", "am_conv_last_variant"):
+            if name in ("am_version", "am_conv_npad", "am_conv_last_variant", "am_set_tuning", "am_get_tuning"):  # return values, not status codes
                 setattr(self, name, fn)
             else:
                 setattr(self, name, self._checked(name, fn))
+        # A/B builds and CI legs pin kernels without code changes: AUTOMOE_TUNE_<KEY>=<int> (keys of am_set_tuning)
+        for key, idx in (("RING", AM_TUNE_RING), ("RING128_MIN_TILES", AM_TUNE_RING128_MIN_TILES), ("WGRAD_RING", AM_TUNE_WGRAD_RING)):
+            v = os.environ.get("AUTOMOE_TUNE_" + key)
+            if v is not None:
+                self.am_set_tuning(idx, int(v))
 
     @staticmethod
     def _checked(name, fn):

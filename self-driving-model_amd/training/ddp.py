@@ -8,10 +8,10 @@ overlaps the rest of backward.  Buckets are contiguous slices of the optimizer's
 world size) is folded into the optimizer's scale pass.  BatchNorm buffers stay rank-local (the reference's
 per-forward buffer broadcast changes nothing for rank 0).
 
-"Gradient complete" comes from two sources, each parameter reporting exactly once per backward: autograd's
-post-accumulate hook (gradients autograd accumulates: conv weights / biases) and runtime.grad_ready() from the
-backward kernels that add straight into ``param.grad`` (Linear / LayerNorm / BatchNorm parameters in direct
-mode, hip/ops.py, hip/conv.py).
+"Gradient complete" comes from two sources: autograd's post-accumulate hook (gradients autograd accumulates: conv
+weights / biases) and runtime.grad_ready() from the backward kernels that add straight into ``param.grad``
+(Linear / LayerNorm / BatchNorm parameters in direct mode, hip/ops.py, hip/conv.py).  A parameter counts once per
+backward (its first report); parameters are not shared between layers on this path.
 
 hipGraph steps: with the "nccl" backend (= RCCL on ROCm) the bucket collectives are CAPTURED with the step --
 event record on the compute stream, wait + all-reduce on the side stream, join before the optimizer -- so a
@@ -86,6 +86,7 @@ class GradBucketReducer:
     def reset(self):
         self._pending = [n for (_, _, n) in self.buckets]
         self._handles = []
+        self._seen = bytearray(len(self._index))
         self._streams = [set() for _ in self.buckets]  # streams whose backward nodes wrote into each bucket
 
     def _on_grad(self, param):
@@ -98,8 +99,13 @@ class GradBucketReducer:
         b = self._bucket_of[idx]
         if self.flat.is_cuda:
             self._streams[b].add(torch.cuda.current_stream())
+        # a parameter written in direct mode is announced by its kernel's call site AND (torch 2.10 runs the post-accumulate
+        # hook even for a gradient the node returned as None) by autograd; both come after its only contribution of this
+        # backward was enqueued, so the first report counts and the second is dropped
+        if self._seen[idx]:
+            return
+        self._seen[idx] = 1
         self._pending[b] -= 1
-        assert self._pending[b] >= 0, "a parameter reported its gradient twice in one backward"
         if self._pending[b] == 0:
             self._launch(b)
 
@@ -193,6 +199,47 @@ def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step
     reducer.paused = reducer.enabled and graph is not None and not in_graph
     reducer.reset()
     return graph, result, in_graph
+
+
+class StepStream:
+    """Every step of a trainer -- the eager ones before the capture, the capture itself, replays and eager fallbacks -- runs on ONE
+    side HIP stream owned by the trainer.
+
+    Why: autograd binds a parameter's AccumulateGrad node to the stream that was current when the node was created, and the node
+    lives as long as any tensor of that iteration's graph does (a loss a caller keeps).  If such a node from an eager step on the
+    DEFAULT stream is still alive when the step is captured on the capture stream, the captured backward accumulates on the
+    default stream behind an event of the capturing stream: the default stream is pulled into the capture and never joined.
+    CUDA reports cudaErrorStreamCaptureUnjoined; HIP (ROCm 7.2) takes a host segfault inside hipStreamEndCapture
+    (scratch/repro_capture_segv.py: "stale" faults, "clean" and "samestream" capture fine).  With all steps on the same
+    stream a surviving node is bound to the capture stream itself.  Trainers also hand out DETACHED loss tensors, so callers
+    cannot keep a graph alive by keeping a loss."""
+
+    def __init__(self, device):
+        dev = torch.device(device)
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+
+    def __enter__(self):
+        if self.stream is None:
+            return self
+        self._outer = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(self._outer)  # inputs the caller produced
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.stream is None:
+            return False
+        self._ctx.__exit__(*exc)
+        self._outer.wait_stream(self.stream)  # results are ordered for the caller's stream; nothing blocks the host
+        return False
+
+
+def detached(losses):
+    """The same values without the autograd graph (see StepStream)."""
+    if isinstance(losses, dict):
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
+    return losses.detach() if isinstance(losses, torch.Tensor) else losses
 
 
 class DataParallel(torch.nn.Module):

@@ -21,7 +21,7 @@ from .. import runtime
 from ..hip import ops as hops
 from ..models.experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, capture_step
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
 from .hungarian_matcher import HungarianMatcher
 from .optim import FusedAdamW
 
@@ -94,6 +94,7 @@ class BDDTrainer:
         self._graph = self._static = self._static_loss = None
         self._reduce_in_graph = False
         self._eager_steps = 0
+        self._step_stream = StepStream(device)  # every step, eager or captured, runs on this stream (training/ddp.py StepStream)
 
     def load_training_state(self, checkpoint):
         if checkpoint.get("optimizer_state_dict") is not None:
@@ -114,8 +115,14 @@ class BDDTrainer:
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
-        loss = self._train_detection_batch(batch) if self.task == "detection" else self._train_segmentation_batch(batch)
-        loss.backward()
+        # conv weight / BatchNorm gradients are added straight into the flat gradient buffer by their kernels (no staging tensor,
+        # no accumulate launch per parameter); the kernels' call sites report to the bucketed all-reduce (runtime.grad_ready)
+        runtime.set_direct_grads(True)
+        try:
+            loss = self._train_detection_batch(batch) if self.task == "detection" else self._train_segmentation_batch(batch)
+            loss.backward()
+        finally:
+            runtime.set_direct_grads(False)
         return loss
 
     def _capture(self, batch):
@@ -124,8 +131,8 @@ class BDDTrainer:
 
         def capture(in_graph):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                loss = self._fwd_bwd(self._static)
+            with torch.cuda.graph(g, stream=self._step_stream.stream, capture_error_mode=mode):
+                loss = detached(self._fwd_bwd(self._static))
                 if in_graph:
                     self.reducer.finish()  # RCCL bucket all-reduces recorded with the step (training/ddp.py)
             return g, loss
@@ -147,6 +154,10 @@ class BDDTrainer:
                    for k, v in self._static.items())
 
     def train_step(self, batch):
+        with self._step_stream:
+            return self._train_step(batch)
+
+    def _train_step(self, batch):
         dev_ok = torch.device(self.device).type == "cuda"
         if self.use_graph and dev_ok and self._graph is None and self._eager_steps >= 2 and self.core.training:
             self._capture(batch)
@@ -172,7 +183,7 @@ class BDDTrainer:
             self._eager_steps += 1
         self.optimizer.step()  # clip_grad_norm_(1.0) folded in
         self.scheduler.step()
-        return loss
+        return detached(loss)
 
     def train_epoch(self, epoch):
         self.model.train()

@@ -18,7 +18,7 @@ import torch.distributed as dist
 from .. import runtime
 from ..models.policy.trajectory_head import TrajectoryPolicy
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, capture_step
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
 from .optim import FusedAdamW
 
 
@@ -54,6 +54,7 @@ class PolicyTrainStep:
         self._graph = self._static = self._static_losses = None
         self._reduce_in_graph = False
         self._eager_steps = 0
+        self._step_stream = StepStream(self.optimizer.flat_p.device)  # training/ddp.py StepStream
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
@@ -71,8 +72,8 @@ class PolicyTrainStep:
 
         def capture(in_graph):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                losses = self._fwd_bwd(self._static)
+            with torch.cuda.graph(g, stream=self._step_stream.stream, capture_error_mode=mode):
+                losses = detached(self._fwd_bwd(self._static))
                 if in_graph:
                     self.reducer.finish()
             return g, losses
@@ -86,6 +87,10 @@ class PolicyTrainStep:
                    for k, v in self._static.items() if isinstance(v, torch.Tensor))
 
     def __call__(self, batch):
+        with self._step_stream:
+            return self._step(batch)
+
+    def _step(self, batch):
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.core.training:
             self._capture(batch)
         if self._graph is not None and self._fits_graph(batch):
@@ -109,7 +114,7 @@ class PolicyTrainStep:
             self.reducer.finish()
             self._eager_steps += 1
         self.optimizer.step()
-        return losses
+        return detached(losses)
 
 
 def train_one_epoch(model, loader, step: PolicyTrainStep, device, epoch_idx: int, epochs: int, rank: int) -> float:

@@ -19,7 +19,7 @@ import torch.nn.functional as F  # noqa: F401  (kept for API parity with the ref
 from .. import runtime
 from ..models.automoe import create_automoe_model
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, capture_step
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
 from .optim import FusedAdamW
 
 
@@ -96,7 +96,7 @@ class GatingTrainStep:
     ones (the reference's gating loader has no drop_last: training/train_gating_network.py:259-267) runs eagerly with the
     same collectives."""
 
-    def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = 25, use_graph=None):
+    def __init__(self, model: nn.Module, config: Dict, bucket_mb: int = None, use_graph=None):
         self.model = model
         self.core = model.module if hasattr(model, "module") else model
         self.config = config
@@ -106,7 +106,8 @@ class GatingTrainStep:
         self.optimizer = FusedAdamW(params, lr=config.get("learning_rate", 1e-4), weight_decay=config.get("weight_decay", 1e-4),
                                     max_norm=1.0)
         self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
-                                         bucket_bytes=bucket_mb << 20, broadcast_from=self.optimizer.flat_p)
+                                         bucket_bytes=None if bucket_mb is None else bucket_mb << 20,
+                                         broadcast_from=self.optimizer.flat_p)  # None: AUTOMOE_BUCKET_MB or 25 MB
         self.optimizer.grad_divisor = float(self.reducer.world)
         if use_graph is None:
             use_graph = os.environ.get("AUTOMOE_HIPGRAPH", "1") != "0"
@@ -116,6 +117,7 @@ class GatingTrainStep:
         self._static_losses = None
         self._reduce_in_graph = False   # the captured step holds its bucket all-reduces (RCCL)
         self._eager_steps = 0
+        self._step_stream = StepStream(self.optimizer.flat_p.device)  # every step, eager or captured, runs on this stream
         # Expert prefetch (frozen experts only): the experts' forward is its own hipGraph on its own stream and runs for the
         # NEXT batch while the rest of this step -- gating / policy forward, backward, all-reduce, optimizer: kernels that
         # are HBM-, atomics- or latency-bound -- is still on the GPU beside the experts' MFMA-bound convolutions.  Frozen
@@ -193,8 +195,8 @@ class GatingTrainStep:
 
         def capture(in_graph):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                losses = self._fwd_bwd(self._static_batch, cache_b)
+            with torch.cuda.graph(g, stream=self._step_stream.stream, capture_error_mode=mode):
+                losses = detached(self._fwd_bwd(self._static_batch, cache_b))  # same storage, no graph kept alive
                 if in_graph:
                     self.reducer.finish()  # records the joins: the replay ends with every bucket reduced
             return g, losses
@@ -262,6 +264,10 @@ class GatingTrainStep:
         the caller's loader writes the next image straight into ``expert_input_buffers`` (before this step is captured: the
         first batch, which the buffer is initialised with).  With frozen experts and a captured step its expert forward is
         launched now and overlaps this step's backward / optimizer; the next call must then be made with exactly that batch."""
+        with self._step_stream:
+            return self._step(batch, next_batch)
+
+    def _step(self, batch, next_batch):
         if self.use_graph and self._graph is None and self._eager_steps >= 2 and self.model.training:
             self._capture(batch)
         if self._graph is not None and self._fits_graph(batch):
@@ -294,7 +300,7 @@ class GatingTrainStep:
             self.reducer.finish()
             self._eager_steps += 1
         self.optimizer.step()
-        return losses
+        return detached(losses)
 
 
 def train_one_epoch(model, loader, optimizer, device, epoch_idx, epochs, rank, config, step: GatingTrainStep = None) -> float:

@@ -42,3 +42,48 @@ def _oracle_built():
     if not os.path.exists(so):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
+# ---- which kernel ran (include/automoe_hip.h am_conv_last_variant): kernel tests pin the kernel their docstring names ----
+KERNELS = {0: "none", 1: "conv_ring_k<256,256>", 2: "conv_ring_k<256,128>", 3: "conv3x3_c64n64_duo_k", 4: "conv3x3_c64n64_wreg_k",
+           5: "conv3x3_c64n64_k", 6: "conv_gemm2_k", 7: "conv_gemm3_k", 8: "conv_gemm_k", 9: "conv_s2d_k", 10: "conv_s2d_pool_k",
+           11: "conv_ring16_k<256,256>", 12: "conv_ring16_k<256,128>", 13: "wgrad_ring_k", 14: "conv_wgrad_k", 15: "conv_s2d_wgrad_k"}
+
+
+def launched_kernel(expect=None, what=""):
+    """Name of the conv kernel the last am_conv_* call of this thread launched; asserts it is (one of) `expect`.
+    AUTOMOE_TEST_RECORD_KERNELS=<file> appends (what, name) lines: how the expectations in the tests were first filled in."""
+    from self_driving_model_amd.hip import lib
+    name = KERNELS.get(lib.get().am_conv_last_variant(), "?")
+    rec = os.environ.get("AUTOMOE_TEST_RECORD_KERNELS")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(f"{what}\t{name}\n")
+    if expect is not None:
+        expect = (expect,) if isinstance(expect, str) else tuple(expect)
+        assert name in expect, f"{what}: launched {name}, the test is written for {expect}"
+    return name
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Parity bookkeeping of tests/test_hip_models.py::_grad_check: how many parameter gradients were compared element-wise
+    with the fp32 oracle, and every one that needed the fp64 arbitration (ill-conditioned train-mode BatchNorm cases)."""
+    mod = sys.modules.get("test_hip_models")
+    if mod is None or not getattr(mod, "COMPARED", None):
+        return
+    import json
+    arb, cmp_ = mod.ARBITRATIONS, mod.COMPARED
+    tr = terminalreporter
+    tr.write_sep("=", "gradient parity: fp64 arbitrations")
+    tr.write_line(f"parameters compared element-wise with the fp32 oracle: {sum(c[1] for c in cmp_)} in {len(cmp_)} checks; "
+                  f"arbitrated against fp64: {len(arb)}")
+    for a in arb:
+        tr.write_line(f"  {a['test']}  {a['param']}: hip vs fp64 {a['hip_vs_fp64']:.2e}, torch-cpu-fp32 vs fp64 {a['torch_fp32_vs_fp64']:.2e} "
+                      f"(missed rtol {a['rtol']:g} / atol {a['atol']:g} against torch-cpu-fp32)")
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_arbitrations.json"), "w") as f:
+            json.dump({"checks": [{"test": c[0], "parameters": c[1], "arbitrated": c[2]} for c in cmp_], "arbitrations": arb}, f, indent=1)
+    except OSError:
+        pass

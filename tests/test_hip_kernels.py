@@ -9,6 +9,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import launched_kernel
+
 pytestmark = pytest.mark.gpu
 
 RT, AT = 1e-3, 1e-5
@@ -57,6 +59,12 @@ CONV_CASES = [
 ]
 
 
+# (case, dtype) -> kernel the forward must launch at these small sizes: the exact-fp32 register-staged kernel in fp32 mode; in f16
+# the two-stage LDS-DMA kernel, except the 3-channel first layers (below the size the space-to-depth patch kernel takes)
+FWD_KERNEL = {(c, torch.float32): "conv_gemm_k" for c in CONV_CASES}
+FWD_KERNEL.update({(c, torch.float16): ("conv_gemm_k" if c[0] == 3 else "conv_gemm2_k") for c in CONV_CASES})
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd_vs_torch(case, dtype):
@@ -83,6 +91,7 @@ def test_conv_fwd_bwd_vs_torch(case, dtype):
         wd, bd = w.to(_dev()).requires_grad_(), b.to(_dev()).requires_grad_()
         cfg = hc._Cfg(spec, hc.PackedWeights(), None, True, 1.0)
         y = hc.conv_bn_act(xd, wd, bd, None, True, None, cfg, False)
+        launched_kernel(FWD_KERNEL.get((case, dtype)), what=f"conv_fwd {case} {dtype}")
         es = 2 if dtype == torch.float16 else 4
         ld = hc.channel_ld(cout, es)
         assert y.shape == (B, yr.shape[2], yr.shape[3], ld)
@@ -376,6 +385,10 @@ def test_adamw_and_clip_vs_torch():
     assert torch.equal(pd, before) and int(skipped) == 1
 
 
+WS_KERNEL = {(2, 180, 320): "conv3x3_c64n64_duo_k", (1, 200, 333): "conv3x3_c64n64_duo_k",
+             (3, 45, 64): "conv_gemm2_k"}  # the small problem stays below the weights-in-registers kernel's size gate
+
+
 @pytest.mark.parametrize("shape", [(2, 180, 320), (3, 45, 64), (1, 200, 333)])
 def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
     """The 64->64 3x3 patch kernel (conv_patch.hip) takes over from the gather-GEMM for large fp16 problems: same
@@ -393,6 +406,7 @@ def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
     stats = torch.zeros(16 * 2 * 64, dtype=torch.float64, device=_dev())
     geom = hc.fwd_geom(s, B, H, W, 64, 64, 2)
     hc.conv_gemm(geom, xd, wp, None, False, y, stats)
+    launched_kernel(WS_KERNEL.get(shape), what=f"c64n64 {shape}")
     torch.cuda.synchronize()
     close(nchw(y, 64), yr, rtol=2e-3, atol=2e-3)
     st = stats.view(16, 2, 64).sum(0).cpu()
@@ -436,6 +450,7 @@ def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
             x = hops.image_to_s2d(img.to(_dev()), torch.float16)
             cfg = hc._Cfg(s, hc.PackedWeights(), bn, True, 1.0)
             y = hc.conv_bn_act(x, wd, None, bn, True, None, cfg, True)
+            launched_kernel("conv_s2d_k", what=f"first layer {spec} fused={fused}")
         hc.flush_bn_counters()
         outs[fused] = (y, bn)
     hc.FUSE_FIRST_LAYER = True
@@ -456,7 +471,9 @@ def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
 
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 2, 186, 181), (256, 256, 3, 1, 1, 8, 96, 100), (128, 256, 3, 2, 1, 2, 370, 361)])
 def test_conv_big_tile_variant_vs_torch(case):
-    """Problems with M >= 65536 rows and N > 64 take the 8-wave 256x128 tile: forward and statistics against torch."""
+    """Problems with M >= 65536 rows take the 8-wave ring kernels -- N = 128: conv_ring_k<256,128> (32x32x16 MFMA), N >= 256:
+    conv_ring16_k<256,256> (16x16x32 MFMA, transposed product) -- forward and statistics against torch; the launched kernel is
+    asserted, so a moved dispatch threshold cannot silently take the test away from them."""
     from self_driving_model_amd.hip import conv as hc
     cin, cout, k, st, pad, B, H, W = case
     g = torch.Generator().manual_seed(cin + H)
@@ -469,6 +486,7 @@ def test_conv_big_tile_variant_vs_torch(case):
     y = torch.zeros(B, OH, OW, cout, dtype=torch.float16, device=_dev())
     stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
     hc.conv_gemm(hc.fwd_geom(s, B, H, W, cin, cout, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), None, False, y, stats)
+    launched_kernel("conv_ring_k<256,128>" if cout == 128 else "conv_ring16_k<256,256>", what=f"big tile {case}")
     torch.cuda.synchronize()
     close(nchw(y, cout), yr, rtol=3e-3, atol=3e-3)
     st_ = stats.view(16, 2, cout).sum(0).cpu()
@@ -553,9 +571,15 @@ def test_first_layer_weight_gradient_kernels_vs_torch(spec):
         dz[..., :cout] = torch.randn(B, geo.OH, geo.OW, cout, generator=torch.Generator().manual_seed(3)).half()
         a = torch.zeros(cout, geo.ntaps * geo.krun, device=_dev())
         hc.conv_wgrad(geo, x, dz.to(_dev()), 1.0, a)
+        launched_kernel("conv_s2d_wgrad_k", what=f"first-layer wgrad {spec}")
         dw = hc.unpack_wgrad(a, s, torch.float16)
     ref = torch.nn.grad.conv2d_weight(img.half().float(), w.shape, dz[..., :cout].float().permute(0, 3, 1, 2).contiguous(), stride=2, padding=pad)
     assert rel_err(dw, ref) < 2e-3, rel_err(dw, ref)
+
+
+S2_DGRAD_KERNEL = {((128, 256, 4, 240, 256), True): "conv_ring16_k<256,256>", ((128, 256, 4, 240, 256), False): "conv_ring16_k<256,256>",
+                   ((64, 128, 2, 320, 320), True): "conv_ring_k<256,128>", ((64, 128, 2, 320, 320), False): "conv_ring_k<256,128>",
+                   ((32, 64, 2, 256, 256), True): "conv_gemm2_k", ((32, 64, 2, 256, 256), False): "conv_gemm2_k"}
 
 
 @pytest.mark.gpu
@@ -587,6 +611,7 @@ def test_fused_stride2_dgrad_vs_parity_class_launches_and_torch(case):
                     assert hc.dgrad_s2_plan(spec, B, H, W, cin, cout, 2) is not None
                 y = hc.conv_bn_act(xd, wd, None, None, False, None, cfg, False)
                 (y[..., :cout].float() * probe.permute(0, 2, 3, 1).to(_dev())).sum().backward()
+                launched_kernel(S2_DGRAD_KERNEL.get((case, fused)), what=f"s2 dgrad {case} fused={fused}")
             grads[fused] = xd.grad.float().cpu()
         finally:
             hc.FUSE_S2_DGRAD = True
@@ -644,7 +669,8 @@ def test_eval_bn_folding_matches_normalise_pass_and_torch(case):
 def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
     """Weight gradients whose contraction is long enough (>= 16384 output pixels, N % 128 == 0, output rows >= 32 pixels) run
     the LDS-DMA ring kernel (conv_wgrad_ring.hip): against torch's conv2d weight gradient and against the register-staged
-    kernel (AM_WGRAD_RING=0 semantics via the module flag), including partial k-tiles, two n-tiles, stride 2 and 1x1."""
+    kernel on the SAME geometry (am_set_tuning(AM_TUNE_WGRAD_RING, 0)), including partial k-tiles, two n-tiles, stride 2 and
+    1x1; both legs assert the kernel they launched."""
     import ctypes
     from self_driving_model_amd.hip import conv as hc
     cin, cout, k, st, pad, B, H, W = case
@@ -662,15 +688,107 @@ def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
     L = hc._L()
     for ring in (1, 0):
         dwp = torch.zeros(cout, geom.ntaps * geom.krun, dtype=torch.float32, device=_dev())
-        if ring:
+        old = L.am_set_tuning(2, ring)  # AM_TUNE_WGRAD_RING: 0 pins the register-staged kernel on the same geometry
+        try:
             hc.conv_wgrad(geom, xd, dyd, 1.0, dwp)
-        else:  # the same geometry with a 31-pixel-wide claim is not expressible: call the old kernel through a sub-16384 split
-            half = B // 2
-            for b0, nb in ((0, half), (half, B - half)):
-                gs = hc.fwd_geom(spec, nb, H, W, cin, cout, 2)
-                if nb * gs.OH * gs.OW >= 16384:
-                    pytest.skip("halves still long enough for the ring kernel")
-                hc.conv_wgrad(gs, xd[b0:b0 + nb].contiguous(), dyd[b0:b0 + nb].contiguous(), 1.0, dwp)
+        finally:
+            L.am_set_tuning(2, old)
+        launched_kernel("wgrad_ring_k" if ring else "conv_wgrad_k", what=f"wgrad {'ring' if ring else 'register-staged'} {case}")
         outs.append(hc.unpack_wgrad(dwp, spec, torch.float16).cpu())
     assert rel_err(outs[0], w.grad) < 2e-3
     assert rel_err(outs[0], outs[1]) < 1e-3
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 96, 100, True), (128, 256, 3, 2, 1, 2, 370, 361, False), (256, 512, 1, 2, 0, 8, 128, 160, False)])
+def test_ring_kernel_generations_agree(case):
+    """conv_ring16_k (AM_TUNE_RING 1 block issue / 2 spread / 3 by wave age) against conv_ring_k (0) through am_set_tuning: the
+    same products summed in fp32 in another order -- outputs equal after f16 rounding up to one ulp on a few elements,
+    statistics to 1e-6 -- with the bias + ReLU epilogue and without, ragged M tiles included."""
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, k, st, pad, B, H, W, with_bias = case
+    L = hc._L()
+    g = torch.Generator().manual_seed(cin + W)
+    x = nhwc(torch.randn(B, cin, H, W, generator=g), torch.float16)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(_dev())
+    bias = torch.randn(cout, generator=g).to(_dev()) if with_bias else None
+    s = hc.ConvSpec(cin, cout, k, st, pad)
+    geom = hc.fwd_geom(s, B, H, W, cin, cout, 2)
+    wp = hc.pack_fwd(w, s, torch.float16)
+    old = L.am_get_tuning(0)
+    res = {}
+    try:
+        for t, name in ((0, "conv_ring_k<256,256>"), (1, "conv_ring16_k<256,256>"), (2, "conv_ring16_k<256,256>"), (3, "conv_ring16_k<256,256>")):
+            L.am_set_tuning(0, t)
+            y = torch.zeros(B, geom.OH, geom.OW, cout, dtype=torch.float16, device=_dev())
+            stats = None if with_bias else torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
+            hc.conv_gemm(geom, x, wp, bias, with_bias, y, stats)
+            launched_kernel(name, what=f"ring generations {case} tuning {t}")
+            torch.cuda.synchronize()
+            res[t] = (y.float().cpu(), None if stats is None else stats.view(16, 2, cout).sum(0).cpu())
+    finally:
+        L.am_set_tuning(0, old)
+    for t in (1, 2, 3):
+        assert rel_err(res[t][0], res[0][0]) < 2e-4, (t, rel_err(res[t][0], res[0][0]))
+        if res[0][1] is not None:
+            np.testing.assert_allclose(res[t][1].numpy(), res[0][1].numpy(), rtol=1e-6, atol=1e-3)
+    yr = F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), w.half().float().cpu(), None if bias is None else bias.cpu(), stride=st, padding=pad)
+    yr = F.relu(yr) if with_bias else yr
+    assert rel_err(res[1][0][:1].permute(0, 3, 1, 2), yr) < 2e-3
+
+
+@pytest.mark.parametrize("case", [(128, 256, 3, 2, 1, 4, 128, 160, torch.float16, "wgrad_ring_k"), (512, 512, 3, 1, 1, 6, 46, 80, torch.float16, "wgrad_ring_k"),
+                                  (64, 64, 3, 1, 1, 2, 96, 128, torch.float16, "conv_wgrad_k"), (256, 14, 1, 1, 0, 3, 23, 40, torch.float16, "conv_wgrad_k"),
+                                  (64, 128, 3, 2, 1, 2, 23, 40, torch.float32, "conv_wgrad_k")])
+def test_wgrad_workspace_form_vs_torch_and_atomic_form(case):
+    """am_conv_wgrad_ws (per-chunk slabs in a caller-owned workspace sized by am_conv_wgrad_workspace_bytes + a summing pass that
+    writes the nn.Conv2d layout) against torch's conv2d weight gradient and against the atomic form + re-layout, for the ring
+    kernel and the register-staged kernel: same values, bitwise reproducible from run to run, `accumulate` adds onto what is
+    there, and the workspace size is what the header says (chunks * N * Ktot * 4 bytes, > 0)."""
+    import ctypes
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, k, st, pad, B, H, W, dtype, kernel = case
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).requires_grad_()
+    if dtype == torch.float16:
+        x = x.half().float()
+    y = F.conv2d(x, w, None, stride=st, padding=pad)
+    dyr = torch.randn(y.shape, generator=g) * 0.5
+    if dtype == torch.float16:
+        dyr = dyr.half().float()
+    (y * dyr).sum().backward()
+    spec = hc.ConvSpec(cin, cout, k, st, pad)
+    es = 2 if dtype == torch.float16 else 4
+    ldo = hc.channel_ld(cout, es)
+    xd, dyd = nhwc(x, dtype), nhwc(dyr, dtype, ld=ldo)
+    geom = hc.fwd_geom(spec, B, H, W, cin, ldo, es)
+    L = hc._L()
+    nbytes = ctypes.c_longlong(0)
+    L.am_conv_wgrad_workspace_bytes(ctypes.byref(geom), hc.dt_code(dtype), ctypes.byref(nbytes))
+    ktot = geom.ntaps * geom.krun
+    assert nbytes.value > 0 and nbytes.value % (cout * ktot * 4) == 0
+    wparam = torch.nn.Parameter(torch.zeros(cout, cin, k, k, device=_dev()))
+    outs = []
+    for _ in range(2):
+        dw = hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec)  # scale 0.5: the loss-scale division
+        launched_kernel(kernel, what=f"wgrad ws {case[:8]}")
+        outs.append(dw.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), "the slab sum must be bitwise reproducible"
+    tol = 2e-3 if dtype == torch.float16 else 1e-5
+    assert rel_err(outs[0], 0.5 * w.grad) < tol, rel_err(outs[0], 0.5 * w.grad)
+    if dtype == torch.float32:
+        close(outs[0], 0.5 * w.grad, rtol=RT, atol=1e-5, what="fp32 weight gradient")
+    # atomic form + re-layout
+    dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=_dev())
+    hc.conv_wgrad(geom, xd, dyd, 0.5, dwp)
+    assert rel_err(hc.unpack_wgrad(dwp, spec, dtype), outs[0]) < 1e-4
+    # direct mode: added straight into the parameter's preallocated gradient
+    wparam.grad = torch.full((cout, cin, k, k), 2.0, device=_dev())
+    runtime.set_direct_grads(True)
+    try:
+        assert hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec) is None
+    finally:
+        runtime.set_direct_grads(False)
+    close(wparam.grad - 2.0, outs[0], rtol=1e-5, atol=1e-5, what="accumulate")

@@ -48,34 +48,48 @@ def _pair(cls_name, seed, *args, **kw):
     return hip.to(_dev()), ref
 
 
-def _grad_check(hip, ref, rtol, atol, skip=(), truth=None):
+ARBITRATIONS = []  # every parameter whose element-wise gradient check was re-judged against fp64 (printed at session end)
+
+
+def _grad_check(hip, ref, rtol, atol, skip=(), truth=None, what=""):
     """Element-wise gradient comparison against the fp32 oracle.
 
     Train-mode BatchNorm over a handful of samples followed by ReLU is ill-conditioned: an activation that is
     ~1e-7 from zero can take a different ReLU branch under a 1-ulp change, which moves every upstream gradient
     by ~1e-2 (torch-CPU fp32 itself is then that far from an fp64 run of the same model).  `truth` (a callable
     returning the fp64 oracle, gradients computed) arbitrates: a parameter that misses the fp32 oracle must be
-    at least as close to the fp64 result as the fp32 oracle is (x3), and never worse than 5e-2 relative L2."""
-    bad = []
+    at least as close to the fp64 result as the fp32 oracle is (x3), and never worse than 5e-2 relative L2.
+    Every arbitration is RECORDED (test, parameter, hip-vs-fp64, torch-fp32-vs-fp64) and listed in the terminal
+    summary and gpurun_out/parity_arbitrations.json; truth=None means strict: any miss fails.  Returns the number
+    of parameters compared."""
+    bad, n_cmp = [], 0
     for (n, p), (n2, q) in zip(hip.named_parameters(), ref.named_parameters()):
         assert n == n2
         if any(s in n for s in skip) or q.grad is None:
             continue
         assert p.grad is not None, n
+        n_cmp += 1
         try:
             close(p.grad, q.grad, rtol=rtol, atol=atol, what=n)
         except AssertionError as e:
             bad.append((n, e))
+    COMPARED.append((what or os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_cmp, len(bad) if truth is not None else 0))
     if not bad:
-        return
+        return n_cmp
     if truth is None:
         raise bad[0][1]
     t = dict(truth().named_parameters())
     r = dict(ref.named_parameters())
     h = dict(hip.named_parameters())
+    test = what or os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
     for n, e in bad:
         e_hip, e_ref = rel_err(h[n].grad, t[n].grad), rel_err(r[n].grad, t[n].grad)
+        ARBITRATIONS.append({"test": test, "param": n, "rtol": rtol, "atol": atol, "hip_vs_fp64": e_hip, "torch_fp32_vs_fp64": e_ref})
         assert e_hip <= max(2e-3, 3 * e_ref) and e_hip < 5e-2, f"{n}: hip vs fp64 {e_hip:.2e}, torch-cpu-fp32 vs fp64 {e_ref:.2e}\n{e}"
+    return n_cmp
+
+
+COMPARED = []  # (test, parameters compared, parameters arbitrated)
 
 
 @pytest.mark.parametrize("train", [False, True])
@@ -1142,3 +1156,243 @@ def test_optimizer_state_and_nuscenes_keys_in_the_reference_layout(tmp_path):
         fresh.load_expert_checkpoints(paths)
     for (n, a), (_, b) in zip(fresh.experts.state_dict().items(), ref4.experts.state_dict().items()):
         assert torch.equal(a.cpu(), b), n
+
+
+# ---- north_star tolerance with NO arbitration: well-conditioned variants of the gradient tests -------------------------------
+# Eval-mode BatchNorm (running statistics: no batch-wide coupling, no 1/sigma amplification of a flipped ReLU) keeps the whole
+# backward well conditioned, so hip fp32 mode must meet rtol 1e-3 / atol 1e-5 element-wise on EVERY parameter gradient with
+# truth=None (any miss fails).  The train-mode tests above keep the fp64 arbitration and report how often it fires.
+STRICT = dict(rtol=1e-3, atol=1e-5)
+
+
+def _eval_bn_with_grads(*models):
+    for m in models:
+        m.eval()  # BatchNorm on running statistics, Dropout off; gradients still flow to every parameter
+        for p in m.parameters():
+            p.requires_grad_(True)
+
+
+@pytest.mark.parametrize("expert", ["BDDDrivableExpert", "BDDSegmentationExpert", "BDDDetectionExpert"])
+def test_expert_gradients_strict_tolerance_eval_bn(expert):
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    from oracle.losses import segmentation_loss
+    ncls = {"BDDDrivableExpert": 3, "BDDSegmentationExpert": 19, "BDDDetectionExpert": 10}[expert]
+    hip, ref = _pair(expert, 131, ncls, False)
+    # running statistics away from their (0, 1) initial values, as after training
+    g = torch.Generator().manual_seed(132)
+    for (n, b), (_, bh) in zip(ref.named_buffers(), hip.named_buffers()):
+        if n.endswith("running_mean"):
+            b.copy_(0.1 * torch.randn(b.shape, generator=g)); bh.copy_(b)
+        elif n.endswith("running_var"):
+            b.copy_(0.5 + torch.rand(b.shape, generator=g)); bh.copy_(b)
+    _eval_bn_with_grads(hip, ref)
+    x = seeded_tensor((2, 3, 64, 96), 133)
+    if expert == "BDDDetectionExpert":
+        o_r = ref(x)
+        pc, pb = seeded_tensor(o_r["class_logits"].shape, 134), seeded_tensor(o_r["bbox_deltas"].shape, 135)
+        ((o_r["class_logits"] * pc).sum() + (o_r["bbox_deltas"] * pb).sum()).backward()
+        with runtime.precision(torch.float32):
+            o = hip(x.to(_dev()))
+            ((o["class_logits"] * pc.to(_dev())).sum() + (o["bbox_deltas"] * pb.to(_dev())).sum()).backward()
+        close(o["class_logits"], o_r["class_logits"], what="class_logits", **STRICT)
+        close(o["bbox_deltas"], o_r["bbox_deltas"], what="bbox_deltas", **STRICT)
+    else:
+        gm = torch.Generator().manual_seed(136)
+        mask = torch.randint(0, ncls, (2, 64, 96), generator=gm)
+        mask[torch.rand(2, 64, 96, generator=gm) < 0.05] = 255
+        segmentation_loss(ref(x), mask).backward()
+        with runtime.precision(torch.float32):
+            y = hip(x.to(_dev()))
+            hops.CrossEntropy2d.apply(y, mask.to(_dev()), 255).backward()
+    n = _grad_check(hip, ref, truth=None, what=f"strict/{expert}", **STRICT)
+    assert n >= 62  # 20 convs + 20 BatchNorms (x2) + the head: every parameter compared, none arbitrated
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_automoe_gradients_strict_tolerance_eval_bn(frozen):
+    """The AutoMoE train step (forward + gating losses + backward) at rtol 1e-3 / atol 1e-5 on every output, every loss term
+    and every parameter gradient, no arbitration: eval-mode BatchNorm in the experts and the policy backbone."""
+    from oracle.losses import gating_losses
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.training.train_gating_network import compute_gating_losses, fused_gating_losses
+    hip, ref = _automoe_pair(150)
+    _eval_bn_with_grads(hip, ref)
+    if frozen:
+        hip.freeze_experts(); ref.freeze_experts()
+    batch = _batch(2, 64, 96, 160)
+    o_r = ref(batch)
+    l_r = gating_losses(o_r, batch["waypoints"], batch["speed"], {})
+    l_r["total_loss"].backward()
+    with runtime.precision(torch.float32):
+        db = {k: v.to(_dev()) for k, v in batch.items()}
+        o = hip(db)
+        l = fused_gating_losses(o, db["waypoints"], db["speed"], {})  # the launch the trainer uses
+        l["total_loss"].backward()
+        l_unfused = compute_gating_losses(o, db["waypoints"], db["speed"], {})
+    for k in ("waypoints", "speed", "speed_seq", "expert_weights", "context_features", "combined_features", "gate_logits"):
+        close(o[k], o_r[k], what=k, **STRICT)
+    for k in l_r:
+        close(l[k], l_r[k], rtol=1e-4, atol=1e-6, what=k)
+        close(l_unfused[k], l_r[k], rtol=1e-4, atol=1e-6, what=k + " (unfused)")
+    n = _grad_check(hip, ref, truth=None, what=f"strict/automoe frozen={frozen}", **STRICT)
+    assert n >= (60 if frozen else 240)
+
+
+def test_drivable_expert_train_mode_bn_b16_reports_arbitrations():
+    """Train-mode BatchNorm at a batch where the statistics are averaged over 16 x 64 x 96 samples per channel: still compared
+    at the strict tolerance; parameters that miss it go to the fp64 arbitration and are listed in the session summary (the
+    count is the honest measure of how far 'green' is from 'within rtol 1e-3 / atol 1e-5' for train-mode BatchNorm)."""
+    import copy
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    from oracle.losses import segmentation_loss
+    hip, ref = _pair("BDDDrivableExpert", 141, 3, False)
+    hip.train(); ref.train()
+    x = seeded_tensor((16, 3, 64, 96), 142)
+    gm = torch.Generator().manual_seed(143)
+    mask = torch.randint(0, 3, (16, 64, 96), generator=gm)
+    ref64 = copy.deepcopy(ref).double()
+    segmentation_loss(ref(x), mask).backward()
+
+    def truth():
+        segmentation_loss(ref64(x.double()), mask).backward()
+        return ref64
+    with runtime.precision(torch.float32):
+        hops.CrossEntropy2d.apply(hip(x.to(_dev())), mask.to(_dev()), 255).backward()
+    _grad_check(hip, ref, truth=truth, what="train-bn/B16 drivable", **STRICT)
+
+
+# ---- BASELINE configs[1] and 4b at their FULL size: size-independent properties ------------------------------------------------
+def _grad_vector(params):
+    return torch.cat([p.grad.detach().flatten().float() for p in params if p.grad is not None])
+
+
+def test_full_size_drivable_expert_train_step_b16_720p():
+    """BASELINE configs[1] at full size (batch 16, 3x720x1280, fp16, hipGraph) where the oracle is too slow: (1) the loss of
+    BDDTrainer.train_step is finite and falls over six steps on a fixed batch; (2) ONE forward + backward in f16 against the
+    same step in fp32 mode (the parity-exact kernels, held to rtol 1e-3 / atol 1e-5 at small sizes above) on the same batch:
+    loss within 2e-3, whole-gradient cosine > 0.97 and relative L2 < 0.3 (the f16 bound of the small-size tests).  These are
+    the shapes that pick wgrad_ring_k, the ring dgrads and conv_s2d_wgrad_k at B = 16."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    from self_driving_model_amd.models.experts import BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = _dev()
+    B, H, W = 16, 720, 1280
+    torch.manual_seed(7)
+    m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
+    b = synthetic.bdd_drivable_batch(B, H, W, 3, dev, seed=1)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    grads, losses1 = {}, {}
+    for dt in (torch.float32, torch.float16):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        with runtime.precision(dt):
+            loss = hops.CrossEntropy2d.apply(m(b["image"]), b["mask"], 255)
+            loss.backward()
+        losses1[dt] = float(loss)
+        grads[dt] = _grad_vector(m.parameters()).cpu()
+        assert torch.isfinite(grads[dt]).all()
+        del loss  # (an autograd graph kept alive across a later capture is what scratch/repro_capture_segv.py is about)
+    assert abs(losses1[torch.float16] - losses1[torch.float32]) < 2e-3 * abs(losses1[torch.float32]) + 1e-4, losses1
+    cos = float(torch.nn.functional.cosine_similarity(grads[torch.float16], grads[torch.float32], dim=0))
+    l2 = float((grads[torch.float16] - grads[torch.float32]).norm() / grads[torch.float32].norm())
+    assert cos > 0.97 and l2 < 0.3, (cos, l2)
+    m.load_state_dict(sd0)
+    m.zero_grad(set_to_none=True)
+    with runtime.precision(torch.float16):
+        loader = synthetic.SyntheticLoader(b, 8)
+        tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 2e-4, "weight_decay": 1e-5, "epochs": 1, "run_name": "t"})
+        losses = [float(tr.train_step(b)) for _ in range(6)]
+        assert tr._graph is not None
+    # (labels are random per pixel: ln 3 is the floor of what six steps can reach, and AdamW's first sign-like updates push
+    # the loss up before it comes down -- so: finite, and falling step after step once the first updates are in)
+    assert all(np.isfinite(losses)) and all(b_ < a_ for a_, b_ in zip(losses[1:], losses[2:])) and losses[-1] < 0.75 * max(losses), losses
+    assert int(tr.optimizer.skipped) == 0
+
+
+def test_full_size_automoe_unfrozen_train_step_b32_720p():
+    """BASELINE configs[3] variant 4b at full size (per-GPU batch 32, 3x720x1280, all three experts trainable, fp16, hipGraph):
+    finite loss falling over six steps on a fixed batch, every expert parameter moved, no skipped update; and one forward +
+    backward in f16 against fp32 mode on the same batch -- loss within 2e-3, gradient cosine > 0.97, relative L2 < 0.3."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep, fused_gating_losses
+    dev = _dev()
+    B, H, W = 32, 720, 1280
+    torch.manual_seed(9)
+    m = create_automoe_model(AUTOMOE_CFG, dev)
+    m.unfreeze_experts()
+    m.train()
+    for d in m.modules():
+        if isinstance(d, torch.nn.Dropout):
+            d.p = 0.0  # the two precisions must see the same network
+    batch = synthetic.carla_sequence_batch(B, H, W, 10, dev, seed=3)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    grads, losses1 = {}, {}
+    for dt in (torch.float32, torch.float16):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        with runtime.precision(dt):
+            loss = fused_gating_losses(m(batch), batch["waypoints"], batch["speed"], {})["total_loss"]
+            loss.backward()
+        losses1[dt] = float(loss)
+        grads[dt] = _grad_vector(m.parameters()).cpu()
+        assert torch.isfinite(grads[dt]).all()
+        del loss
+        torch.cuda.empty_cache()
+    assert abs(losses1[torch.float16] - losses1[torch.float32]) < 2e-3 * abs(losses1[torch.float32]) + 1e-4, losses1
+    cos = float(torch.nn.functional.cosine_similarity(grads[torch.float16], grads[torch.float32], dim=0))
+    l2 = float((grads[torch.float16] - grads[torch.float32]).norm() / grads[torch.float32].norm())
+    assert cos > 0.97 and l2 < 0.3, (cos, l2)
+    m.load_state_dict(sd0)
+    m.zero_grad(set_to_none=True)
+    with runtime.precision(torch.float16):
+        step = GatingTrainStep(m, {"learning_rate": 4e-4, "weight_decay": 1e-4})
+        expert0 = {k: p.detach().clone() for k, p in m.experts.named_parameters()}
+        losses = [float(step(step.input_buffers or batch)["total_loss"]) for _ in range(6)]
+        assert step._graph is not None and step._graph_experts is None  # trainable experts: no prefetch graph
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert int(step.optimizer.skipped) == 0
+    moved = sum(1 for k, p in m.experts.named_parameters() if not torch.equal(p.detach(), expert0[k]))
+    assert moved == len(expert0), (moved, len(expert0))
+
+
+def test_capture_survives_a_caller_that_keeps_every_loss():
+    """Root cause of the hipStreamEndCapture host fault (round 1 gpurun_out/segv.log; scratch/repro_capture_segv.py): an autograd
+    graph of an earlier eager step on ANOTHER stream, still alive at capture time, keeps AccumulateGrad nodes bound to that
+    stream; the captured backward then drags the default stream into the capture unjoined.  The trainers therefore (1) run every
+    step on their own stream and (2) return detached losses.  This test is the naive loop that used to be one step away from
+    the fault: it keeps every returned loss object alive across the capture, for the gating step (expert / policy streams forked
+    inside the capture) and the expert trainer."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.models.experts import BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+    dev = _dev()
+    kept = []
+    with runtime.precision(torch.float16):
+        torch.manual_seed(3)
+        m = create_automoe_model(AUTOMOE_CFG, dev)
+        m.freeze_experts()
+        m.train()
+        batch = {k: v.to(dev) for k, v in _batch(2, 64, 96, 400).items()}
+        step = GatingTrainStep(m, {"learning_rate": 1e-3, "weight_decay": 1e-4}, use_graph=True)
+        for i in range(5):
+            kept.append(step(batch, next_batch=batch))
+        assert step._graph is not None
+        assert all(v.grad_fn is None and not v.requires_grad for d in kept for v in d.values() if isinstance(v, torch.Tensor))
+        e = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
+        b = synthetic.bdd_drivable_batch(2, 128, 160, 3, dev, seed=3)
+        loader = synthetic.SyntheticLoader(b, 8)
+        tr = BDDTrainer("drivable", e, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t", "use_graph": True})
+        for i in range(5):
+            kept.append(tr.train_step(b))
+        assert tr._graph is not None and all(t.grad_fn is None for t in kept[5:])
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(t)) for t in kept[5:])
