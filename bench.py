@@ -246,6 +246,11 @@ def main():
             step_b = GatingTrainStep(model, TRAIN_CFG)
             dt_b = timed_steps(lambda: step_b(batch), 3, 4, False)  # warm-up covers the hipGraph capture
             others["cfg4b_unfrozen_B32_img_s"] = round(args.batch * 3 / dt_b, 2)
+            del step_b
+            # the parity-exact mode (exact-fp32 MFMA kernels, the ones held to rtol 1e-3 / atol 1e-5 against the oracle): what the
+            # north_star tolerance costs in throughput on the same 4a step
+            if args.precision == "fp16":
+                others["cfg4a_fp32_mode_B32_img_s"] = bench_fp32_mode(args.batch, batch)
         except Exception as e:  # noqa: BLE001
             others["error"] = repr(e)[:200]
         out["other_configs"] = others
@@ -253,9 +258,36 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
+        try:  # the GPU test session's gradient-parity bookkeeping (tests/conftest.py), as last committed under profiles/
+            pa = json.load(open(os.path.join(ROOT, "profiles", "r02_parity_arbitrations.json")))
+            out["parity"] = {"gradients_compared_elementwise": sum(c["parameters"] for c in pa["checks"]),
+                             "arbitrations": len(pa["arbitrations"]),
+                             "strict_checks_without_arbitration": sum(1 for c in pa["checks"] if c["test"].startswith("strict/")),
+                             "source": "profiles/r02_parity_arbitrations.json"}
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+def bench_fp32_mode(B, batch):
+    """The 4a train step of the timed line in fp32 compute mode (runtime.precision(float32): conv_gemm_k<float> on
+    v_mfma_f32_32x32x2_f32, fp32 activations) -- the kernels the parity tests hold to the north_star tolerance."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.automoe import create_automoe_model
+    from self_driving_model_amd.training.train_gating_network import GatingTrainStep
+    dev = batch["image"].device
+    with runtime.precision(torch.float32):
+        torch.manual_seed(0)
+        m = create_automoe_model(MODEL_CFG, dev)
+        m.freeze_experts()
+        m.train()
+        st = GatingTrainStep(m, TRAIN_CFG)
+        dt = timed_steps(lambda: st(st.input_buffers or batch, next_batch=True), 3, 4, False)
+    del st, m
+    torch.cuda.empty_cache()
+    return round(B * 3 / dt, 2)
 
 
 def bench_drivable(B, steps, warmup):

@@ -117,11 +117,14 @@ int am_conv_last_variant(void);
  *   AM_TUNE_RING   0: conv_ring_k (v_mfma_f32_32x32x16_f16), 1: conv_ring16_k (16x16x32, transposed product, pieces issued as a
  *                  block), 2: conv_ring16_k with the LDS-DMA pieces spread between the MFMA groups.
  *   AM_TUNE_RING128_MIN_TILES   fewest 256x128 tiles (M/256 * N/128) for which conv_ring_k<256,128> is dispatched.
- *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k. */
+ *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k.
+ *   AM_TUNE_WGRAD_MAX_SLABS   am_conv_wgrad_ws keeps one slab per pixel chunk up to this many chunks; beyond it the chunks add
+ *                  atomically into ONE zero-filled slab (0: always; a huge value: never). */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
-#define AM_TUNE_COUNT 3
+#define AM_TUNE_WGRAD_MAX_SLABS 3
+#define AM_TUNE_COUNT 4
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 
@@ -141,8 +144,10 @@ int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, const void* d
  * contraction stores its partial dW tile with plain stores into its own slab of `workspace`; a second pass sums the slabs and
  * writes dw_oihw[n][c][t] (the nn.Conv2d weight layout, c < cin, t = kh*KW + kw), = or += by `accumulate` -- no device-scope fp32
  * atomics (they bound the atomic form at ~1.3 TB/s of added bytes), no zero-filled staging tensor, no re-layout pass, and a
- * bitwise reproducible sum.  am_conv_wgrad_workspace_bytes() gives the size for a geometry (0: that geometry runs a kernel
- * without a slab form -- the 3-channel first layers -- and am_conv_wgrad_ws returns AM_ERR_UNSUPPORTED: use am_conv_wgrad).
+ * bitwise reproducible sum.  Geometries whose contraction splits into more than AM_TUNE_WGRAD_MAX_SLABS pixel chunks (tiny dW,
+ * millions of pixels) keep the atomics but aim them at ONE slab the call zero-fills itself, and share the second pass (not
+ * bitwise reproducible there).  am_conv_wgrad_workspace_bytes() gives the size for a geometry (0: that geometry runs a kernel
+ * without a workspace form -- the 3-channel first layers -- and am_conv_wgrad_ws returns AM_ERR_UNSUPPORTED: use am_conv_wgrad).
  * `workspace` must be 16-byte aligned; it needs no initialisation. */
 int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, long long* bytes);
 int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale, void* workspace,

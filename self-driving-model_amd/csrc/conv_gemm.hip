@@ -539,19 +539,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 }
 
 // Second pass of am_conv_wgrad_ws: out = (accumulate ? out : 0) + scale * sum over the pixel chunks' slabs, written in the
-// nn.Conv2d weight layout out[n][c][t] (OIHW: t = kh * KW + kw) from the packed k = t * krun + c.  A thread owns one packed
-// element: slab reads are coalesced along k; the scattered 4-byte writes touch a few MB at most.
-__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int N, int Ktot, int krun,
+// nn.Conv2d weight layout out[n][c][t] (OIHW: t = kh * KW + kw) from the packed k = t * krun + c.  The re-layout is a permutation
+// INSIDE an output-channel row, so a workgroup owns (a part of) one row: slab reads coalesced along k, the permutation through
+// LDS, the read-modify-write of `out` coalesced again.  grid = (parts, N); a part covers whole taps' worth of channels.
+constexpr int WR_CH = 32;  // channels per part: a part handles channels [c0, c0 + WR_CH) of every tap -> 4 * WR_CH * ntaps floats of LDS
+
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int Ktot, int krun,
                                                       int cin, int ntaps, float scale, float* __restrict__ out, int accumulate) {
-  const long long total = (long long)N * Ktot;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / Ktot), k = (int)(i - (long long)n * Ktot);
-    const int t = k / krun, c = k - t * krun;
-    if (c >= cin) continue;
-    float sum = 0.f;
-    for (int s = 0; s < nchunks; ++s) sum += ws[(size_t)s * ws_stride + i];
-    float* o = out + ((size_t)n * cin + c) * ntaps + t;
-    *o = accumulate ? *o + sum * scale : sum * scale;
+  extern __shared__ float row[];  // [4 chunk groups][cpart * ntaps] in output order
+  const int n = blockIdx.y, c0 = blockIdx.x * WR_CH;
+  const int cpart = min(WR_CH, cin - c0);
+  const int nel = cpart * ntaps;
+  const float* src = ws + (size_t)n * Ktot;
+  // wave w sums the chunks s = w, w + 4, ...: a wave-instruction reads 64 consecutive packed k of one slab (256 B), eight of
+  // them in flight per lane (a layer with few output channels has hundreds of short slabs: latency, not bytes, is its bound)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = lane; i < nel; i += 64) {
+    const int t = i / cpart, c = i - t * cpart;
+    const float* col = src + t * krun + c0 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int sidx = w;
+    for (; sidx + 28 < nchunks; sidx += 32) {
+      a0 += col[(size_t)sidx * ws_stride];
+      a1 += col[(size_t)(sidx + 4) * ws_stride];
+      a2 += col[(size_t)(sidx + 8) * ws_stride];
+      a3 += col[(size_t)(sidx + 12) * ws_stride];
+      a4 += col[(size_t)(sidx + 16) * ws_stride];
+      a5 += col[(size_t)(sidx + 20) * ws_stride];
+      a6 += col[(size_t)(sidx + 24) * ws_stride];
+      a7 += col[(size_t)(sidx + 28) * ws_stride];
+    }
+    for (; sidx < nchunks; sidx += 4) a0 += col[(size_t)sidx * ws_stride];
+    row[w * nel + c * ntaps + t] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  __syncthreads();
+  float* o = out + ((size_t)n * cin + c0) * ntaps;
+  for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+    const float v = ((row[i] + row[nel + i]) + (row[2 * nel + i] + row[3 * nel + i])) * scale;
+    o[i] = accumulate ? o[i] + v : v;
   }
 }
 
@@ -609,6 +634,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_RING */ 1,
     /* AM_TUNE_RING128_MIN_TILES */ 192,
     /* AM_TUNE_WGRAD_RING */ 1,
+    /* AM_TUNE_WGRAD_MAX_SLABS */ 32,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }
@@ -717,6 +743,12 @@ extern "C" int am_conv_wgrad(const am_conv_geom* g, int dtype, const void* x, co
   return wgrad_dispatch(g, dtype, x, dy, scale, dw, nullptr, 0, false, static_cast<hipStream_t>(stream));
 }
 
+// Slabs the workspace form uses for a geometry: the kernel's pixel chunks while they are few (each slab is written and read
+// once: S * |dW| * 8 bytes of traffic), else ONE zero-filled slab that the kernel's atomic form accumulates into -- with
+// hundreds of chunks (small dW, long contraction) the slabs' traffic costs more than the atomics it removes (measured on the
+// layer1 / layer2 / policy shapes: +20..+50 us per launch; layer4 / head shapes with 7-13 slabs: -10..-18 us).
+static int ws_slabs(int chunks) { return chunks <= am_tuning(AM_TUNE_WGRAD_MAX_SLABS) ? chunks : 1; }
+
 extern "C" int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, long long* bytes) {
   int rc = check_geom(g, dtype);
   if (rc != AM_OK) return rc;
@@ -725,7 +757,7 @@ extern "C" int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, l
   if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
   const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
   if (chunks < 0) return chunks;
-  *bytes = (long long)chunks * g->N * g->ntaps * g->krun * 4;
+  *bytes = (long long)ws_slabs(chunks) * g->N * g->ntaps * g->krun * 4;
   return AM_OK;
 }
 
@@ -741,15 +773,21 @@ extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x,
   const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
   if (chunks < 0) return chunks;
   if (chunks == 0) return AM_ERR_UNSUPPORTED;  // first-layer kernel: atomic form only (caller: am_conv_wgrad + its own unpack)
+  const int slabs = ws_slabs(chunks);
   const long long Ktot = (long long)g->ntaps * g->krun, stride = (long long)g->N * Ktot;
-  if (!workspace || workspace_bytes < chunks * stride * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return AM_ERR_ARG;
-  rc = wgrad_dispatch(g, dtype, x, dy, 1.f, nullptr, static_cast<float*>(workspace), stride, false, s);
+  if (!workspace || workspace_bytes < slabs * stride * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return AM_ERR_ARG;
+  float* ws = static_cast<float*>(workspace);
+  if (slabs == chunks) {
+    rc = wgrad_dispatch(g, dtype, x, dy, 1.f, nullptr, ws, stride, false, s);
+  } else {  // many short chunks: atomics into one zeroed slab (a memset node under capture), re-laid out by the same second pass
+    if (hipMemsetAsync(ws, 0, (size_t)stride * 4, s) != hipSuccess) return AM_ERR_LAUNCH;
+    rc = wgrad_dispatch(g, dtype, x, dy, 1.f, ws, nullptr, 0, false, s);
+  }
   if (rc != AM_OK) return rc;
-  const long long total = stride;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((int)blocks), dim3(256), 0, s, static_cast<const float*>(workspace), chunks, stride, g->N, (int)Ktot,
-                     g->krun, cin, g->ntaps, scale, dw_oihw, accumulate);
+  const int parts = am_cdiv(cin, WR_CH);
+  const size_t lds = 4 * (size_t)(cin < WR_CH ? cin : WR_CH) * g->ntaps * sizeof(float);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(parts, g->N), dim3(256), lds, s, ws, slabs, stride, (int)Ktot, g->krun, cin, g->ntaps, scale,
+                     dw_oihw, accumulate);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

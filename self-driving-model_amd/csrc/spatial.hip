@@ -200,51 +200,77 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
   }
 }
 
-// gather form: every input element sums the (at most 4) windows whose arg-max it is
+// Block form of the same gather (what am_maxpool3x3s2_bwd launches): a thread owns the 2x2 block of input pixels
+// (2Y + py, 2X + px) of one 16-byte channel chunk.  Window (oy, ox) covers rows 2oy-1 .. 2oy+1, so the block is touched by
+// exactly the four windows (Y + wy, X + wx), wy, wx in {0, 1}, and pixel (py, px) sits in window (wy, wx) at kh = py + 1 - 2wy,
+// kw = px + 1 - 2wx (valid when 0 <= kh, kw <= 2: an even row / column belongs to one window only).  Four dY loads, four
+// arg-max loads, four stores per thread, no data-dependent control flow: 422 -> ~2x faster than one pixel per thread on the stem
+// map ([16,360,640,64]: 650 MB of algorithmic traffic).  Contributions are summed in the order of the per-pixel form.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_k(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
-                                                     int B, int IH, int IW, int OH, int OW, int C) {
+__global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
+                                                           int B, int IH, int IW, int OH, int OW, int C) {
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;
-  const long long total = (long long)B * IH * IW * cpr;
+  const int BH = (IH + 1) / 2, BW = (IW + 1) / 2;
+  const long long total = (long long)B * BH * BW * cpr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % cpr);
     long long t = i / cpr;
-    const int ix = (int)(t % IW); t /= IW;
-    const int iy = (int)(t % IH);
-    const int b = (int)(t / IH);
-    float acc[E];
+    const int X = (int)(t % BW); t /= BW;
+    const int Y = (int)(t % BH);
+    const int b = (int)(t / BH);
+    float g[2][2][E];
+    uint8_t a[2][2][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    // windows oy with oy*2-1+kh == iy, kh in 0..2
+    for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ty = iy + 1 - kh;
-      if (ty < 0 || (ty & 1)) continue;
-      const int oy = ty >> 1;
-      if (oy >= OH) continue;
+      for (int wx = 0; wx < 2; ++wx) {
+        const int oy = Y + wy, ox = X + wx;
+        if (oy < OH && ox < OW) {
+          const long long ooff = (((long long)b * OH + oy) * OW + ox) * C + ch * E;
+          const uint4 raw = *reinterpret_cast<const uint4*>(dy + ooff);
+          const T* v = reinterpret_cast<const T*>(&raw);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tx = ix + 1 - kw;
-        if (tx < 0 || (tx & 1)) continue;
-        const int ox = tx >> 1;
-        if (ox >= OW) continue;
-        const long long ooff = (((long long)b * OH + oy) * OW + ox) * C + ch * E;
-        const uint4 raw = *reinterpret_cast<const uint4*>(dy + ooff);
-        const T* g = reinterpret_cast<const T*>(&raw);
-        uint8_t a[E];
-        if constexpr (E == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + ooff);
-        else *reinterpret_cast<unsigned*>(a) = *reinterpret_cast<const unsigned*>(arg + ooff);
+          for (int e = 0; e < E; ++e) g[wy][wx][e] = am_to_f32(v[e]);
+          if constexpr (E == 8) *reinterpret_cast<uint2*>(a[wy][wx]) = *reinterpret_cast<const uint2*>(arg + ooff);
+          else *reinterpret_cast<unsigned*>(a[wy][wx]) = *reinterpret_cast<const unsigned*>(arg + ooff);
+        } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-          if (a[e] == kh * 3 + kw) acc[e] += am_to_f32(g[e]);
+          for (int e = 0; e < E; ++e) { g[wy][wx][e] = 0.f; a[wy][wx][e] = 255; }
+        }
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      const int iy = 2 * Y + py;
+      if (iy >= IH) continue;
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int ix = 2 * X + px;
+        if (ix >= IW) continue;
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        // per-pixel form order: kh ascending = window row Y+1 (kh = 0) before Y (kh = 1 or 2); kw likewise
+#pragma unroll
+        for (int wy = 1; wy >= 0; --wy) {
+          const int kh = py + 1 - 2 * wy;
+          if (kh < 0) continue;
+#pragma unroll
+          for (int wx = 1; wx >= 0; --wx) {
+            const int kw = px + 1 - 2 * wx;
+            if (kw < 0) continue;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              if (a[wy][wx][e] == kh * 3 + kw) acc[e] += g[wy][wx][e];
+          }
+        }
+        uint4 outraw;
+        T* o = reinterpret_cast<T*>(&outraw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(acc[e]);
+        *reinterpret_cast<uint4*>(dx + (((long long)b * IH + iy) * IW + ix) * C + ch * E) = outraw;
       }
     }
-    uint4 outraw;
-    T* o = reinterpret_cast<T*>(&outraw);
-#pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(acc[e]);
-    *reinterpret_cast<uint4*>(dx + i * E) = outraw;
   }
 }
 
@@ -576,10 +602,10 @@ extern "C" int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* arg
   const int es = dtype == AM_F16 ? 2 : 4;
   if (!DT_OK(dtype) || !dy || !dx || !argmax || (C * es) % 16 != 0) return AM_ERR_ARG;
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
-  const long long total = (long long)B * IH * IW * (C * es / 16);
+  const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * (C * es / 16);
   if (total == 0) return AM_OK;
-  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C);
-  else hipLaunchKernelGGL(maxpool_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C);
+  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_bwd_block_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C);
+  else hipLaunchKernelGGL(maxpool_bwd_block_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
