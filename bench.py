@@ -192,14 +192,15 @@ def main():
         # the clock the chip held inside the dominant kernel (s_memtime vs the 100 MHz s_memrealtime, workgroup 0 of the last
         # 256x256 ring launch): the 2.5 PFLOP/s spec peak is quoted at 2.4 GHz
         import ctypes
-        clk = (ctypes.c_longlong * 3)()
+        clk = (ctypes.c_longlong * 8)()
         in_kernel = None
         try:
             hconv._L().am_diag_ring_clock(clk, hconv.stream())
             if clk[1] > 0 and clk[2] > 0:
                 ghz = clk[0] / (clk[1] * 10.0)  # cycles per ns
                 in_kernel = {"clock_ghz": round(ghz, 3), "cycles_per_kstep": round(clk[0] / clk[2], 1), "mfma_floor_cycles_per_kstep": 1024,
-                             "peak_at_clock_tflops": round(PEAK_F16_TFLOPS * ghz / 2.4, 1)}
+                             "peak_at_clock_tflops": round(PEAK_F16_TFLOPS * ghz / 2.4, 1), "ksteps": int(clk[2]),
+                             "prologue_cycles": int(clk[3]), "epilogue_cycles": int(clk[4])}
         except Exception as e:  # noqa: BLE001
             in_kernel = {"error": repr(e)[:120]}
         step._graph, step.use_graph = saved

@@ -119,19 +119,23 @@ int am_conv_last_variant(void);
  *   AM_TUNE_RING128_MIN_TILES   fewest 256x128 tiles (M/256 * N/128) for which conv_ring_k<256,128> is dispatched.
  *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k.
  *   AM_TUNE_WGRAD_MAX_SLABS   am_conv_wgrad_ws keeps one slab per pixel chunk up to this many chunks; beyond it the chunks add
- *                  atomically into ONE zero-filled slab (0: always; a huge value: never). */
+ *                  atomically into ONE zero-filled slab (0: always; a huge value: never).
+ *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256. */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
 #define AM_TUNE_WGRAD_MAX_SLABS 3
-#define AM_TUNE_COUNT 4
+#define AM_TUNE_RING_SHORT_K 4
+#define AM_TUNE_COUNT 5
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 
-/* Diagnostic (bench.py roofline leg): what workgroup 0 of the last conv_ring_k<256,256> launch measured inside its K-loop --
- * out[0] shader-clock cycles (s_memtime), out[1] ticks of the constant 100 MHz clock (s_memrealtime), out[2] K-steps (the
- * MFMA floor is 1024 cycles per K-step).  out[0] / out[1] * 100 MHz = the clock the chip held under that kernel.
- * Synchronises `stream`. */
+/* Diagnostic (bench.py roofline leg): what workgroup 0 of the last 256x256 ring launch measured with s_memtime --
+ * out[0] shader-clock cycles of its K-loop, out[1] ticks of the constant 100 MHz clock (s_memrealtime) over the same span,
+ * out[2] K-steps (the MFMA floor is 1024 cycles per K-step), out[3] cycles from kernel entry to the K-loop (address set-up, the
+ * first two tiles' flight), out[4] cycles from the K-loop's end to the last output store issued (statistics, staging, stores);
+ * out[3], out[4] are 0 for the conv_ring_k generation.  out[0] / out[1] * 100 MHz = the clock the chip held under that kernel.
+ * `out` holds 5 values.  Synchronises `stream`. */
 int am_diag_ring_clock(long long* out, am_stream_t stream);
 
 /* Weight gradient of the same gather-GEMM (torch conv2d backward w.r.t. weight):
@@ -283,6 +287,37 @@ int am_gate_combine_bwd(const float* logits, const float* const* processed, int 
 int am_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, unsigned long long seed,
                    const long long* dev_step, am_stream_t stream);
 int am_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, am_stream_t stream);
+
+/* Grouped forms ("the MoE tail in a handful of launches").  The tail of AutoMoE.forward (automoe.py:189-233 ->
+ * expert_extractors.py:30-34, context_features.py:143-149, gating_network.py:13-20,38-44,93-100,168, trajectory_head.py:44-53) is
+ * ~13 DEPENDENT stages, each with 2-5 INDEPENDENT branches: one extractor MLP / output processor per expert, the context
+ * encoders, the two policy heads.  One call = one launch for all branches of a stage (backward: two launches -- input
+ * gradients, parameter gradients); the dependent stages stay separate launches (a cut at every all-to-all seam).
+ *   linear:    y = dropout_p(relu?(x W^T + b)); the reference's Linear -> ReLU -> Dropout triples run as one epilogue.  The dropout
+ *              mask is the counter-based hash of am_dropout_fwd on (seed, *dev_step, m*N + n); it is not stored: y == 0 <=> dropped
+ *              or rectified, so backward takes dz = dy * gscale * (yact > 0) with yact = y and gscale = 1 / (1 - p).
+ *   backward:  dx (= or +=, dx_accumulate) = dz W;  dW += dz^T x;  dbias += colsum(dz).  NULL dx / dW skip that gradient.
+ *   layernorm: am_layernorm_fwd / _bwd per member (dgamma / dbeta accumulate).
+ * count <= AM_TAIL_MAX_GROUP members, all with the same row count M (the batch). */
+#define AM_TAIL_MAX_GROUP 8
+typedef struct am_tail_linear {
+  const float* x; const float* W; const float* bias; float* y;                 /* forward */
+  const float* dy; const float* yact; float* dx; float* dW; float* dbias;      /* backward (yact, dx, dW, dbias may be NULL) */
+  int32_t ldx, ldy, lddy, ldya, lddx;
+  int32_t N, K, relu, dx_accumulate;
+  float drop_p, gscale;
+  uint64_t seed;
+} am_tail_linear;
+typedef struct am_tail_layernorm {
+  const float* x; const float* gamma; const float* beta; float* y; float* mean; float* rstd;   /* forward (mean / rstd saved) */
+  const float* dy; float* dx; float* dgamma; float* dbeta;                                     /* backward (dx or dgamma+dbeta may be NULL) */
+  int32_t ldx, ldy, lddy, lddx, D;
+  float eps;
+} am_tail_layernorm;
+int am_moe_tail_linear_fwd(const am_tail_linear* group, int count, int M, const long long* dev_step, am_stream_t stream);
+int am_moe_tail_linear_bwd(const am_tail_linear* group, int count, int M, am_stream_t stream);
+int am_moe_tail_layernorm_fwd(const am_tail_layernorm* group, int count, int M, am_stream_t stream);
+int am_moe_tail_layernorm_bwd(const am_tail_layernorm* group, int count, int M, am_stream_t stream);
 
 /* Gating-stage objective (training/train_gating_network.py:21-76 compute_gating_losses) and its gradient in one launch:
  * parts6 = {ade, fde, speed, smoothness, load_balancing, entropy}, total = coef6 . parts6 (one float);

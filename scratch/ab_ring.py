@@ -79,14 +79,14 @@ for name, s, IH, IW in layers:
     for v in VARIANTS:  # in-kernel clock and cycles per K-step of workgroup 0 (256x256 tiles only)
         L.am_set_tuning(0, v)
         hc.conv_gemm(g, x, wp, None, False, y, stats)
-        c = (ctypes.c_longlong * 3)()
+        c = (ctypes.c_longlong * 8)()
         L.am_diag_ring_clock(c, hc.stream())
-        clk[v] = (c[0] / max(c[2], 1), c[0] / max(c[1], 1) / 10.0) if L.am_conv_last_variant() in (1, 11) else None
+        clk[v] = (c[0] / max(c[2], 1), c[0] / max(c[1], 1) / 10.0, c[3], (c[5], c[6], c[7], c[4]), c[0]) if L.am_conv_last_variant() in (1, 11) else None
     line = f"{name:24s} M={B*OH*OW:7d} K={s.cin*s.k*s.k:5d} N={s.cout:4d} "
     for v in VARIANTS:
         t = sorted(times[v]); med, mn = t[len(t) // 2], t[0]
         tot[v] += med
-        line += f"| {names[v]} {med*1e3:7.1f} us {fl/med/1e9:6.0f} TF (min {mn*1e3:6.1f}) " + (f"[{clk[v][0]:.0f} cyc/kstep @{clk[v][1]:.2f} GHz] " if clk[v] else "")
+        line += f"| {names[v]} {med*1e3:7.1f} us {fl/med/1e9:6.0f} TF (min {mn*1e3:6.1f}) " + (f"[{clk[v][0]:.0f} cyc/kstep @{clk[v][1]:.2f} GHz; pro {clk[v][2]} loop {clk[v][4]} epi {clk[v][3]}] " if clk[v] else "")
     print(line, flush=True)
 L.am_set_tuning(0, 0)
 # head conv (115 x 2 tiles of 256x128): the ring kernel below one workgroup per CU vs the two-stage kernel

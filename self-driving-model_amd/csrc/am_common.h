@@ -54,6 +54,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 static inline int am_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// n / d for n < 2^31 as one v_mul_hi_u32 and a shift: mul = ceil(2^(31 + l) / d), l = ceil(log2 d); the error of the rounded-up
+// reciprocal, mul * d - 2^(31 + l) < d <= 2^l, times n < 2^31 stays below 2^(31 + l), so the quotient is exact.  d = 1: mul = 0.
+__device__ __forceinline__ unsigned am_fastdiv(unsigned n, unsigned mul, unsigned sh) { return mul ? __umulhi(n, mul) >> sh : n; }
+static inline void am_fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  *mul = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+  *sh = l - 1;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: launchers keep one "done" flag per device
 // (a benign race: two threads may both set the same value).
 constexpr int AM_MAX_DEVICES = 64;

@@ -28,7 +28,9 @@ struct RingParams {
   double* stats;
   int M, nk, kpt, Ktot, relu, mtiles, ntiles;
   unsigned x_bytes, w_bytes;
+  unsigned hw_mul, hw_sh, mw_mul, mw_sh;  // n / (MH*MW) and n / MW as mulhi + shift (am_fastdiv: exact for n < 2^31)
   int tap_off[RING_MAX_TAPS];  // byte offset of tap t relative to the row's base pixel
+  int tap_yx[RING_MAX_TAPS];   // (dy << 16) | (dx & 0xffff)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -67,26 +69,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane loader state: instruction j of this wave covers tile rows (wid*AI + j)*16 + lane/4 ----
+  // (prologue and epilogue run once per tile on all waves: divisions are mulhi + shift with host-made reciprocals, the padding
+  // test of a tap sits in tap_offsets(), once per tap, instead of a ntaps x AI loop up front -- see conv_ring16.hip)
   const int lrow = lane >> 2, cpos = lane & 3;
-  unsigned a_off[AI], a_mask[AI], b_off[BI];
-  const int hw = g.MH * g.MW;
+  unsigned a_off[AI], b_off[BI];
+  int a_iy[AI], a_ix[AI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int r = (wid * AI + j) * RPI + lrow;
     const int c = cpos ^ ((r >> 2) & 3);  // source chunk for this LDS position
-    const int m = m0 + r;
-    unsigned mask = 0, off = 0;
-    if (m < p.M) {
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int my = rem / g.MW, mx = rem - my * g.MW;
-      const int iy0 = my * g.iys, ix0 = mx * g.ixs;
-      off = (unsigned)((((img * g.IH + iy0) * g.IW + ix0) * g.ldi + g.x_coff) * 2 + c * 16);
-      for (int t = 0; t < g.ntaps; ++t)
-        mask |= (((unsigned)(iy0 + g.dy[t]) < (unsigned)g.IH && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.IW) ? 1u : 0u) << t;
-    }
-    a_off[j] = off;
-    a_mask[j] = mask;
+    const unsigned m = (unsigned)(m0 + r);
+    const unsigned img = am_fastdiv(m, p.hw_mul, p.hw_sh);
+    const unsigned rem = m - img * (unsigned)(g.MH * g.MW);
+    const unsigned my = am_fastdiv(rem, p.mw_mul, p.mw_sh), mx = rem - my * (unsigned)g.MW;
+    const int iy0 = (int)my * g.iys, ix0 = (int)mx * g.ixs;
+    a_off[j] = (unsigned)((((img * g.IH + iy0) * g.IW + ix0) * g.ldi + g.x_coff) * 2 + c * 16);
+    a_iy[j] = (int)m < p.M ? iy0 : -(1 << 20);  // rows past M: far outside every image
+    a_ix[j] = ix0;
   }
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
@@ -94,9 +93,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     const int c = cpos ^ ((r >> 2) & 3);
     b_off[j] = (unsigned)((n0 + r) * p.Ktot * 2 + c * 16);  // rows past the packed matrix are out of range: zeros
   }
-  int tapv = 0;  // lane t holds tap t's byte offset: one v_readlane per K-step instead of a kernarg load (or a scratch table)
+  int tapv = 0, tapyx = 0;  // lane t holds tap t's byte offset / (dy, dx): one v_readlane per tap instead of a kernarg load
 #pragma unroll
-  for (int t = 0; t < RING_MAX_TAPS; ++t) tapv = (lane == t) ? p.tap_off[t] : tapv;
+  for (int t = 0; t < RING_MAX_TAPS; ++t) {
+    tapv = (lane == t) ? p.tap_off[t] : tapv;
+    tapyx = (lane == t) ? p.tap_yx[t] : tapyx;
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -112,8 +114,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   unsigned a_vo[AI];
   auto tap_offsets = [&](int tap) {
     const int toff = __builtin_amdgcn_readlane(tapv, tap);
+    const int yx = __builtin_amdgcn_readlane(tapyx, tap);
+    const int tdy = yx >> 16, tdx = (int)(short)(yx & 0xffff);
 #pragma unroll
-    for (int j = 0; j < AI; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1u) ? a_off[j] + (unsigned)toff : OOB;
+    for (int j = 0; j < AI; ++j) {
+      const bool ok = (unsigned)(a_iy[j] + tdy) < (unsigned)g.IH && (unsigned)(a_ix[j] + tdx) < (unsigned)g.IW;
+      a_vo[j] = ok ? a_off[j] + (unsigned)toff : OOB;
+    }
   };
   auto issue_tile = [&](int kk, int tap, int kin, int stage) {
     char* As = smem + stage * STAGE + wid * (AI * 1024);
@@ -216,16 +223,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   }
 
   // ---- epilogue: BN statistics from the accumulators, bias, ReLU, LDS-staged 16-byte stores ----
-  for (int r = tid; r < BM; r += NTH) {  // output pixel of every tile row
-    const int m = m0 + r;
-    int op = -1;
-    if (m < p.M) {
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int my = rem / g.MW, mx = rem - my * g.MW;
-      op = (img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0;
+  for (int r = tid; r < BM; r += NTH) {  // element offset of every tile row's output pixel (the launcher checks it fits 31 bits)
+    const unsigned m = (unsigned)(m0 + r);
+    int off = -1;
+    if ((int)m < p.M) {
+      const unsigned img = am_fastdiv(m, p.hw_mul, p.hw_sh);
+      const unsigned rem = m - img * (unsigned)(g.MH * g.MW);
+      const unsigned my = am_fastdiv(rem, p.mw_mul, p.mw_sh), mx = rem - my * (unsigned)g.MW;
+      off = (int)(((img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0) * g.ldo + g.y_coff);
     }
-    opix_s[r] = op;
+    opix_s[r] = off;
   }
 
   if (p.stats != nullptr) {
@@ -267,7 +274,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
       atomicAdd(st + g.N + n0 + tid, q);
     }
   }
-  __syncthreads();
+  // (LDS reads done; the fp64 atomics stay in flight: __syncthreads() would wait for their round trip)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   {
     constexpr int SP = TN * 64 + 16;
     char* stg = smem + 8192 + wid * (TM * 32) * SP;  // past the stats scratch and the output-pixel table
@@ -303,17 +313,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     __builtin_amdgcn_wave_barrier();
     constexpr int CPRW = TN * 4;
     const int ncols = (g.N + 7) & ~7;
+    constexpr int NIT = TM * TN * 2;
+    // all LDS reads first (the accumulators are dead), then the stores back to back; 64 % CPRW == 0: a lane keeps its column chunk
+    int offv[NIT];
+    uint4 dat[NIT];
 #pragma unroll
-    for (int it = 0; it < TM * TN * 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int q = it * 64 + lane;
       const int row = q / CPRW, cc = q - row * CPRW;
-      const int op = opix_s[wm * TM * 32 + row];
-      const int col0 = n0 + wn * TN * 32 + cc * 8;
-      // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
-      const size_t seg = (g.osplit > 0 && col0 >= g.osplit) ? (size_t)(g.osplit_stride - g.osplit) : 0;
-      if (op >= 0 && col0 < ncols)
-        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0 + seg) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
+      offv[it] = opix_s[wm * TM * 32 + row];
+      dat[it] = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
     }
+    const int col0 = n0 + wn * TN * 32 + (lane % CPRW) * 8;
+    // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
+    const int seg = (g.osplit > 0 && col0 >= g.osplit) ? g.osplit_stride - g.osplit : 0;
+    const bool col_ok = col0 < ncols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (offv[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(y + (unsigned)(offv[it] + col0 + seg)) = dat[it];
   }
 }
 
@@ -371,10 +388,17 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   p.mtiles = p.ntiles = 0;
   p.x_bytes = (unsigned)x_bytes;
   p.w_bytes = (unsigned)w_bytes;
-  for (int t = 0; t < RING_MAX_TAPS; ++t)
+  for (int t = 0; t < RING_MAX_TAPS; ++t) {
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
+    p.tap_yx[t] = t < g->ntaps ? (int)(((unsigned)(unsigned short)g->dy[t] << 16) | (unsigned short)g->dx[t]) : (int)0x80008000u;
+  }
+  if (((long long)g->B * g->OH * g->OW + 1) * g->ldo + g->osplit_stride + g->y_coff >= (1ll << 31)) return AM_ERR_UNSUPPORTED;  // 31-bit output offsets
+  am_fastdiv_make((unsigned)(g->MH * g->MW), &p.hw_mul, &p.hw_sh);
+  am_fastdiv_make((unsigned)g->MW, &p.mw_mul, &p.mw_sh);
   const long long mt256 = (p.M + 255) / 256;
-  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) return launch_ring<256, 256, 2, 4>(p, s);
+  // (a contraction of a few K-steps -- the 1x1 / stride-2 shortcut convolutions -- is all prologue and epilogue: two 256x128
+  // workgroups per CU overlap one's epilogue with the other's loads, one 256x256 workgroup cannot)
+  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K)) return launch_ring<256, 256, 2, 4>(p, s);
   static int n128 = -1;
   if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
   // 256x128 tiles run two workgroups per CU (72 KiB of LDS each); below one workgroup per CU a lone workgroup still has its CU's
@@ -390,6 +414,7 @@ int am_diag_ring16_clock(long long* out);  // conv_ring16.hip
 extern "C" int am_diag_ring_clock(long long* out, void* stream) {
   if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return AM_ERR_LAUNCH;
   if (am_tuning(AM_TUNE_RING) > 0) return am_diag_ring16_clock(out);
+  out[3] = out[4] = 0;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(amr::g_ring_clk), 3 * sizeof(long long)) != hipSuccess) return AM_ERR_LAUNCH;
   return AM_OK;
 }

@@ -24,7 +24,8 @@
 
 namespace amr16 {
 
-__device__ long long g_clk[3];  // diagnostic: cycles, 100 MHz ticks, K-steps of workgroup 0's K-loop (last 256x256 launch)
+__device__ long long g_clk[8];  // diagnostic (workgroup 0 of the last launch): K-loop cycles, 100 MHz ticks, K-steps, cycles from kernel entry to the
+                                // K-loop, cycles from the K-loop's end to the last store issued
 
 constexpr int MAX_TAPS = 9;
 constexpr unsigned OOB = 0x80000000u;  // offsets at or above every buffer's num_records
@@ -38,7 +39,9 @@ struct Params {
   double* stats;
   int M, nk, kpt, Ktot, relu, mtiles, ntiles;
   unsigned x_bytes, w_bytes;
+  unsigned hw_mul, hw_sh, mw_mul, mw_sh;  // n / (MH*MW) and n / MW as mulhi + shift (fastdiv: exact for n < 2^31)
   int tap_off[MAX_TAPS];  // byte offset of tap t relative to the row's base pixel
+  int tap_yx[MAX_TAPS];   // (dy << 16) | (dx & 0xffff)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
   static_assert(NW == 8 && TM >= 2 && TM % 2 == 0 && TN >= NLOAD && AI >= 1 && BI >= 1 && (BN / RPI) % NW == 0 && (BM / RPI) % NW == 0, "tile");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const long long t_entry = clock64();
 
   const am_conv_geom& g = p.g;
   T* __restrict__ y = static_cast<T*>(p.y);
@@ -76,26 +80,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane loader state: piece j of this wave covers tile rows (wid*AI + j)*16 + lane/4 ----
+  // (the prologue and the epilogue run once per 256x256 tile on all eight waves: with ~1300-cycle K-steps and 36-144 of them per
+  // tile every few hundred instructions here are per cent of the launch -- divisions are mulhi + shift with host-made
+  // reciprocals, the per-tap padding test sits in tap_offsets() (once per tap) instead of a 9 x AI loop up front)
   const int lrow = lane >> 2, cpos = lane & 3;
-  unsigned a_off[AI], a_mask[AI], b_off[BI];
-  const int hw = g.MH * g.MW;
+  unsigned a_off[AI], b_off[BI];
+  int a_iy[AI], a_ix[AI];  // input pixel of tap (0, 0); rows past M: far outside every image
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int r = (wid * AI + j) * RPI + lrow;
     const int c = cpos ^ swz(r);  // source chunk for this LDS position
-    const int m = m0 + r;
-    unsigned mask = 0, off = 0;
-    if (m < p.M) {
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int my = rem / g.MW, mx = rem - my * g.MW;
-      const int iy0 = my * g.iys, ix0 = mx * g.ixs;
-      off = (unsigned)((((img * g.IH + iy0) * g.IW + ix0) * g.ldi + g.x_coff) * 2 + c * 16);
-      for (int t = 0; t < g.ntaps; ++t)
-        mask |= (((unsigned)(iy0 + g.dy[t]) < (unsigned)g.IH && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.IW) ? 1u : 0u) << t;
-    }
-    a_off[j] = off;
-    a_mask[j] = mask;
+    const unsigned m = (unsigned)(m0 + r);
+    const unsigned img = am_fastdiv(m, p.hw_mul, p.hw_sh);
+    const unsigned rem = m - img * (unsigned)(g.MH * g.MW);
+    const unsigned my = am_fastdiv(rem, p.mw_mul, p.mw_sh), mx = rem - my * (unsigned)g.MW;
+    const int iy0 = (int)my * g.iys, ix0 = (int)mx * g.ixs;
+    a_off[j] = (unsigned)((((img * g.IH + iy0) * g.IW + ix0) * g.ldi + g.x_coff) * 2 + c * 16);
+    a_iy[j] = (int)m < p.M ? iy0 : -(1 << 20);
+    a_ix[j] = ix0;
   }
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
@@ -103,23 +105,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     const int c = cpos ^ swz(r);
     b_off[j] = (unsigned)((n0 + r) * p.Ktot * 2 + c * 16);  // rows past the packed matrix are out of range: zeros
   }
-  int tapv = 0;  // lane t holds tap t's byte offset
+  int tapv = 0, tapyx = 0;  // lane t holds tap t's byte offset / its (dy, dx)
 #pragma unroll
-  for (int t = 0; t < MAX_TAPS; ++t) tapv = (lane == t) ? p.tap_off[t] : tapv;
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+  for (int t = 0; t < MAX_TAPS; ++t) {
+    tapv = (lane == t) ? p.tap_off[t] : tapv;
+    tapyx = (lane == t) ? p.tap_yx[t] : tapyx;
+  }
 
   unsigned a_vo[AI];
   auto tap_offsets = [&](int tap) {
     const int toff = __builtin_amdgcn_readlane(tapv, tap);
+    const int yx = __builtin_amdgcn_readlane(tapyx, tap);
+    const int tdy = yx >> 16, tdx = (int)(short)(yx & 0xffff);
 #pragma unroll
-    for (int j = 0; j < AI; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1u) ? a_off[j] + (unsigned)toff : OOB;
+    for (int j = 0; j < AI; ++j) {
+      const bool ok = (unsigned)(a_iy[j] + tdy) < (unsigned)g.IH && (unsigned)(a_ix[j] + tdx) < (unsigned)g.IW;
+      a_vo[j] = ok ? a_off[j] + (unsigned)toff : OOB;  // outside the image: out of the buffer's range -> the hardware writes zeros
+    }
   };
   // piece j of tile (kk, kin): j < AI pixels, else weights
   auto issue_piece = [&](int j, int kk, int kin, int stage) {
@@ -152,6 +154,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
   issue_next();
   issue_next();
   if (young) issue_next();  // the younger half runs one tile further ahead: its slot is right behind each barrier
+
+  f32x4 acc[TN][TM];  // (zeroed while the first tiles are in flight)
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
   // fragment addressing: lane reads row (lane & 15) of its 16-row sub-tile, chunk (lane >> 4) ^ swz(row); sub-tiles are 16 rows
   // apart, which leaves swz unchanged: one base address, immediate offsets
@@ -227,10 +237,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
   if (kk < nk) kstep(wA, wB);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the two tiles issued past the end, the fragments read past the end
   __syncthreads();  // all fragment reads done before the epilogue reuses the stage buffers
+  const long long t_loop_end = clock64();
   if (diag) {
-    g_clk[0] = clock64() - c0;
+    g_clk[0] = t_loop_end - c0;
     g_clk[1] = wall_clock64() - w0;
     g_clk[2] = nk;
+    g_clk[3] = c0 - t_entry;
   }
 
   // ---- epilogue ----
@@ -238,16 +250,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
   // partial sums [col][s|q][wm*16 + pixel lane] and, after the barrier that ends their use, one staging area per wave
   int* opix_s = reinterpret_cast<int*>(smem);
   float* red = reinterpret_cast<float*>(smem + 4096);
-  for (int r = tid; r < BM; r += NTH) {  // output pixel of every tile row
-    const int m = m0 + r;
-    int op = -1;
-    if (m < p.M) {
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int my = rem / g.MW, mx = rem - my * g.MW;
-      op = (img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0;
+  for (int r = tid; r < BM; r += NTH) {  // element offset of every tile row's output pixel (the launcher checks it fits 31 bits)
+    const unsigned m = (unsigned)(m0 + r);
+    int off = -1;
+    if ((int)m < p.M) {
+      const unsigned img = am_fastdiv(m, p.hw_mul, p.hw_sh);
+      const unsigned rem = m - img * (unsigned)(g.MH * g.MW);
+      const unsigned my = am_fastdiv(rem, p.mw_mul, p.mw_sh), mx = rem - my * (unsigned)g.MW;
+      off = (int)(((img * g.OH + my * g.oys + g.oy0) * g.OW + mx * g.oxs + g.ox0) * g.ldo + g.y_coff);
     }
-    opix_s[r] = op;
+    opix_s[r] = off;
   }
 
   const int cg = lane >> 4, pl = lane & 15;  // channel group (4 channels each) and pixel lane of the accumulator map
@@ -255,6 +267,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     // per-channel sum / sum of squares over this lane's TM pixels (rows past M were fetched as zeros), one partial per
     // (wave row, pixel lane) through LDS; slot p ^ 16*(cg & 1) keeps the two channel groups of a 32-lane half on different banks
     constexpr int SL = WM * 16;
+    constexpr int CS = 2 * SL + 4;  // floats per column: s[SL] | q[SL] | 16 B pad -- consecutive columns start four banks apart, so the
+                                    // 16-byte reads of the column owners below are conflict free (unpadded: every lane on one bank, 4.4k cycles)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       f32x4 sv = acc[tn][0], qv = acc[tn][0] * acc[tn][0];
@@ -267,27 +281,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = wn * TN * 16 + tn * 16 + cg * 4 + r;
-        red[(col * 2 + 0) * SL + slot] = sv[r];
-        red[(col * 2 + 1) * SL + slot] = qv[r];
+        red[col * CS + slot] = sv[r];
+        red[col * CS + SL + slot] = qv[r];
       }
     }
     __syncthreads();
+    if (diag) g_clk[5] = clock64() - t_loop_end;
     if (tid < BN && n0 + tid < g.N) {
       double s = 0.0, q = 0.0;
-      const float4* rs = reinterpret_cast<const float4*>(red + (tid * 2 + 0) * SL);
-      const float4* rq = reinterpret_cast<const float4*>(red + (tid * 2 + 1) * SL);
+      const float4* rs = reinterpret_cast<const float4*>(red + tid * CS);
+      const float4* rq = reinterpret_cast<const float4*>(red + tid * CS + SL);
 #pragma unroll
-      for (int a = 0; a < SL / 4; ++a) {
+      for (int a = 0; a < SL / 4; ++a) {  // four partials in fp32 (each already a sum over TM pixels), then fp64
         const float4 u = rs[a], v = rq[a];
-        s += (double)u.x + (double)u.y + (double)u.z + (double)u.w;
-        q += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        s += (double)((u.x + u.y) + (u.z + u.w));
+        q += (double)((v.x + v.y) + (v.z + v.w));
       }
       double* st = p.stats + (size_t)(lb % AM_STATS_REPLICAS) * 2 * g.N;
       atomicAdd(st + n0 + tid, s);
       atomicAdd(st + g.N + n0 + tid, q);
     }
   }
-  __syncthreads();
+  // the partial sums are read (lgkmcnt), the staging area below may overwrite them; the fp64 atomics stay in flight -- a
+  // __syncthreads() here would wait for their round trip to the memory side (vmcnt(0): ~4.4k of the epilogue's 12k cycles)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (diag) g_clk[6] = clock64() - t_loop_end;
   {
     constexpr int WCOLS = TN * 16;          // channels per wave (64)
     constexpr int SP = WCOLS * 2 + 16;      // staging row pitch in bytes
@@ -323,20 +343,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     // the wave reads back what its own lanes wrote: LDS executes a wave's accesses in order, so draining the writes is enough
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (diag) g_clk[7] = clock64() - t_loop_end;
     constexpr int CPRW = WCOLS / 8;  // 16-byte chunks per row
     const int ncols = (g.N + 7) & ~7;
+    constexpr int NIT = TM * 16 * CPRW / 64;
+    // all LDS reads first (the accumulators are dead: registers to spare), then the stores back to back
+    int offv[NIT];
+    uint4 dat[NIT];
 #pragma unroll
-    for (int it = 0; it < TM * 16 * CPRW / 64; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int q = it * 64 + lane;
       const int row = q / CPRW, cc = q - row * CPRW;
-      const int op = opix_s[wm * TM * 16 + row];
-      const int col0 = n0 + wn * WCOLS + cc * 8;
-      // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
-      const size_t seg = (g.osplit > 0 && col0 >= g.osplit) ? (size_t)(g.osplit_stride - g.osplit) : 0;
-      if (op >= 0 && col0 < ncols)
-        *reinterpret_cast<uint4*>(y + (size_t)op * g.ldo + g.y_coff + col0 + seg) = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
+      offv[it] = opix_s[wm * TM * 16 + row];
+      dat[it] = *reinterpret_cast<const uint4*>(stg + row * SP + cc * 16);
     }
+    const int cc_l = lane % CPRW;
+    const int col0 = n0 + wn * WCOLS + cc_l * 8;  // (64 % CPRW == 0: a lane keeps its column chunk in every iteration)
+    // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
+    const int seg = (g.osplit > 0 && col0 >= g.osplit) ? g.osplit_stride - g.osplit : 0;
+    const bool col_ok = col0 < ncols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (offv[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(y + (unsigned)(offv[it] + col0 + seg)) = dat[it];
   }
+  if (diag) g_clk[4] = clock64() - t_loop_end;
 }
 
 template <int BM, int BN, int WM, int WN, int SCHED>
@@ -346,7 +376,7 @@ int launch(const Params& p0, hipStream_t s) {
   p.mtiles = am_cdiv(p.M, BM);
   p.ntiles = am_cdiv(p.g.N, BN);
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr size_t RED = (size_t)BN * 2 * (WM * 16) * 4, STG = (size_t)WM * WN * (TM * 16) * (TN * 32 + 16);
+  constexpr size_t RED = (size_t)BN * (2 * (WM * 16) + 4) * 4, STG = (size_t)WM * WN * (TM * 16) * (TN * 32 + 16);
   constexpr size_t EPI = 4096 + (RED > STG ? RED : STG);
   const size_t lds = 3 * STAGE > EPI ? 3 * STAGE : EPI;
   static_assert(EPI <= 160 * 1024 && BM <= 1024, "epilogue LDS");
@@ -385,10 +415,16 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
   p.mtiles = p.ntiles = 0;
   p.x_bytes = (unsigned)x_bytes;
   p.w_bytes = (unsigned)w_bytes;
-  for (int t = 0; t < MAX_TAPS; ++t)
+  for (int t = 0; t < MAX_TAPS; ++t) {
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
+    p.tap_yx[t] = t < g->ntaps ? (int)(((unsigned)(unsigned short)g->dy[t] << 16) | (unsigned short)g->dx[t]) : (int)0x80008000u;  // past the last tap: far outside
+  }
+  // 31-bit element offsets of the output, split rows included
+  if (((long long)g->B * g->OH * g->OW + 1) * g->ldo + g->osplit_stride + g->y_coff >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
+  am_fastdiv_make((unsigned)(g->MH * g->MW), &p.hw_mul, &p.hw_sh);
+  am_fastdiv_make((unsigned)g->MW, &p.mw_mul, &p.mw_sh);
   const long long mt256 = (p.M + 255) / 256;
-  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200) {
+  if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K)) {
     if (tile_out) *tile_out = 1;
     return variant == 2 ? launch<256, 256, 2, 4, 2>(p, s) : variant == 1 ? launch<256, 256, 2, 4, 1>(p, s) : launch<256, 256, 2, 4, 0>(p, s);
   }
@@ -398,5 +434,5 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
 }
 
 int am_diag_ring16_clock(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(amr16::g_clk), 3 * sizeof(long long)) == hipSuccess ? AM_OK : AM_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(amr16::g_clk), 8 * sizeof(long long)) == hipSuccess ? AM_OK : AM_ERR_LAUNCH;
 }

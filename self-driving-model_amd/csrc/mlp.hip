@@ -408,6 +408,191 @@ __global__ __launch_bounds__(256) void gating_losses_k(const GatingLossArgs a) {
   }
 }
 
+
+// ---- grouped forms: several INDEPENDENT layers of the MoE tail in one launch (blockIdx.z picks the layer) --------------------
+// The tail is ~13 dependent stages, but every stage has 2-5 parallel branches (one extractor / processor MLP per expert, the
+// context encoder, the two policy heads); as separate launches each branch costs a 5-17 us kernel of its own.
+struct LinGroup { am_tail_linear p[AM_TAIL_MAX_GROUP]; };
+struct LnGroup { am_tail_layernorm p[AM_TAIL_MAX_GROUP]; };
+
+// y = dropout(relu(x W^T + b)): linear_fwd_k's wave-per-(column, 8-row chunk) scheme; the dropout of the reference's
+// Linear -> ReLU -> Dropout triples is applied in the epilogue (same counter-based hash as dropout_fwd_k, element index m*N + n),
+// so the mask is recoverable from the stored output (zero <=> dropped or rectified): backward needs no mask tensor.
+__global__ __launch_bounds__(256) void linear_group_fwd_k(const LinGroup grp, int M, const long long* __restrict__ dev_step) {
+  const am_tail_linear& d = grp.p[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int N = d.N, K = d.K;
+  if (n >= N) return;
+  const int m0 = blockIdx.y * MB;
+  if (m0 >= M) return;
+  const float* w = d.W + (size_t)n * K;
+  const float* xr[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) xr[i] = d.x + (size_t)min(m0 + i, M - 1) * d.ldx;
+  float acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+  const bool vec = (K % 4 == 0) && (d.ldx % 4 == 0) && (((uintptr_t)d.x | (uintptr_t)d.W) % 16 == 0);
+  if (vec) {
+#pragma unroll 2
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr[i] + k);
+        acc[i] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+      }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float wv = w[k];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i] += wv * xr[i][k];
+    }
+  }
+  const float b = d.bias ? d.bias[n] : 0.f;
+  unsigned long long seed = d.seed;
+  if (dev_step) seed += (unsigned long long)dev_step[0] * 0xD1B54A32D192ED03ULL;
+  const float inv = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const float sum = wave_sum(acc[i]);
+    if (lane == 0 && m0 + i < M) {
+      float v = sum + b;
+      if (d.relu) v = fmaxf(v, 0.f);
+      if (d.drop_p > 0.f) v = hash_u32(seed, (unsigned long long)(m0 + i) * N + n) >= thr ? v * inv : 0.f;
+      d.y[(size_t)(m0 + i) * d.ldy + n] = v;
+    }
+  }
+}
+
+// dx (+)= dz W, dz = dy * gscale * (yact > 0): linear_bwd_input_k per group member (dynamic LDS sized for the widest N)
+__global__ __launch_bounds__(1024) void linear_group_bwd_input_k(const LinGroup grp, int M) {
+  const am_tail_linear& d = grp.p[blockIdx.z];
+  if (d.dx == nullptr) return;
+  extern __shared__ float sm[];
+  const int N = d.N, K = d.K;
+  if ((int)blockIdx.x * 64 >= K) return;
+  float* dz = sm;
+  float* red = sm + (size_t)MB * N;
+  const int kx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx;
+  const int m0 = blockIdx.y * MB;
+  if (m0 >= M) return;
+  for (int e = threadIdx.x; e < MB * N; e += 1024) {
+    const int i = e / N, n = e - i * N;
+    float g = 0.f;
+    if (m0 + i < M) {
+      g = d.dy[(size_t)(m0 + i) * d.lddy + n] * d.gscale;
+      if (d.yact && !(d.yact[(size_t)(m0 + i) * d.ldya + n] > 0.f)) g = 0.f;
+    }
+    dz[e] = g;
+  }
+  __syncthreads();
+  float acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+  const int nper = (N + BI_SLICES - 1) / BI_SLICES;
+  const int nb = slice * nper, ne = min(N, nb + nper);
+  if (k < K) {
+#pragma unroll 4
+    for (int n = nb; n < ne; ++n) {
+      const float wv = d.W[(size_t)n * K + k];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i] += dz[i * N + n] * wv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MB; ++i) red[(slice * MB + i) * 64 + kx] = acc[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < MB * 64; e += 1024) {
+    const int i = e >> 6, kk = e & 63;
+    const int ko = blockIdx.x * 64 + kk;
+    if (m0 + i < M && ko < K) {
+      float v = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < BI_SLICES; ++sl) v += red[(sl * MB + i) * 64 + kk];
+      float* o = d.dx + (size_t)(m0 + i) * d.lddx + ko;
+      *o = d.dx_accumulate ? *o + v : v;
+    }
+  }
+}
+
+// dW[n][k] += sum_m dz[m][n] x[m][k], dbias[n] += sum_m dz[m][n]: thread per (n, k), grid (ceil(Kmax/256), Nmax, group)
+__global__ __launch_bounds__(256) void linear_group_bwd_weight_k(const LinGroup grp, int M) {
+  const am_tail_linear& d = grp.p[blockIdx.z];
+  if (d.dW == nullptr) return;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (n >= d.N || k >= d.K) return;
+  float acc = 0.f, bacc = 0.f;
+  for (int m = 0; m < M; ++m) {
+    float g = d.dy[(size_t)m * d.lddy + n] * d.gscale;
+    if (d.yact && !(d.yact[(size_t)m * d.ldya + n] > 0.f)) g = 0.f;
+    acc += g * d.x[(size_t)m * d.ldx + k];
+    bacc += g;
+  }
+  d.dW[(size_t)n * d.K + k] += acc;
+  if (d.dbias && k == 0) d.dbias[n] += bacc;
+}
+
+__global__ __launch_bounds__(256) void layernorm_group_fwd_k(const LnGroup grp, int M) {
+  const am_tail_layernorm& d = grp.p[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int D = d.D;
+  const float* xr = d.x + (size_t)m * d.ldx;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { const float t = xr[i] - mu; q += t * t; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + d.eps);
+  for (int i = lane; i < D; i += 64) d.y[(size_t)m * d.ldy + i] = (xr[i] - mu) * rs * d.gamma[i] + d.beta[i];
+  if (lane == 0) { d.mean[m] = mu; d.rstd[m] = rs; }
+}
+
+// blockIdx.y == 0: input gradient (wave per row); blockIdx.y == 1: parameter gradients (thread per column), one launch for both
+__global__ __launch_bounds__(256) void layernorm_group_bwd_k(const LnGroup grp, int M) {
+  const am_tail_layernorm& d = grp.p[blockIdx.z];
+  const int D = d.D;
+  if (blockIdx.y == 0) {
+    if (d.dx == nullptr) return;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float mu = d.mean[m], rs = d.rstd[m];
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      const float g = d.dy[(size_t)m * d.lddy + i] * d.gamma[i];
+      a += g;
+      b += g * (d.x[(size_t)m * d.ldx + i] - mu) * rs;
+    }
+    a = wave_sum(a) / (float)D;
+    b = wave_sum(b) / (float)D;
+    for (int i = lane; i < D; i += 64) {
+      const float g = d.dy[(size_t)m * d.lddy + i] * d.gamma[i];
+      const float xh = (d.x[(size_t)m * d.ldx + i] - mu) * rs;
+      d.dx[(size_t)m * d.lddx + i] = rs * (g - a - xh * b);
+    }
+  } else {
+    if (d.dgamma == nullptr || d.dbeta == nullptr) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float g = d.dy[(size_t)m * d.lddy + i];
+      a += g * (d.x[(size_t)m * d.ldx + i] - d.mean[m]) * d.rstd[m];
+      b += g;
+    }
+    d.dgamma[i] += a;
+    d.dbeta[i] += b;
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -519,6 +704,86 @@ extern "C" int am_gating_losses(const float* wp, const float* twp, int B, int T,
   a.use_lb = use_lb; a.use_ent = use_ent;
   a.total = total; a.parts = parts6; a.g_wp = g_wp; a.g_spd = g_spd; a.g_w = g_w;
   hipLaunchKernelGGL(gating_losses_k, dim3(1), dim3(256), 0, ST(stream), a);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+
+// ---- grouped MoE-tail entries (include/automoe_hip.h am_moe_tail_*) ----------------------------------------------------------
+extern "C" int am_moe_tail_linear_fwd(const am_tail_linear* group, int count, int M, const long long* dev_step, am_stream_t stream) {
+  if (!group || count < 1 || count > AM_TAIL_MAX_GROUP || M < 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  LinGroup g;
+  int nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    const am_tail_linear& d = group[i];
+    if (!d.x || !d.W || !d.y || d.N <= 0 || d.K <= 0 || d.drop_p < 0.f || d.drop_p >= 1.f) return AM_ERR_ARG;
+    g.p[i] = d;
+    nmax = d.N > nmax ? d.N : nmax;
+  }
+  hipLaunchKernelGGL(linear_group_fwd_k, dim3(am_cdiv(nmax, 4), am_cdiv(M, MB), count), dim3(256), 0, ST(stream), g, M, dev_step);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_moe_tail_linear_bwd(const am_tail_linear* group, int count, int M, am_stream_t stream) {
+  if (!group || count < 1 || count > AM_TAIL_MAX_GROUP || M < 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  LinGroup g;
+  int nmax = 0, kmax_in = 0, kmax_w = 0, nmax_w = 0;
+  for (int i = 0; i < count; ++i) {
+    const am_tail_linear& d = group[i];
+    if (!d.dy || !d.W || !d.x || d.N <= 0 || d.K <= 0 || d.N > 65535) return AM_ERR_ARG;
+    g.p[i] = d;
+    if (d.dx) { nmax = d.N > nmax ? d.N : nmax; kmax_in = d.K > kmax_in ? d.K : kmax_in; }
+    if (d.dW) { kmax_w = d.K > kmax_w ? d.K : kmax_w; nmax_w = d.N > nmax_w ? d.N : nmax_w; }
+  }
+  if (kmax_in > 0) {
+    const size_t lds = sizeof(float) * ((size_t)MB * nmax + (size_t)BI_SLICES * MB * 64);
+    if (lds > 150 * 1024) return AM_ERR_UNSUPPORTED;
+    static bool attr_done_dev[AM_MAX_DEVICES] = {};
+    bool& attr_done = attr_done_dev[am_current_device()];
+    if (lds > 64 * 1024 && !attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_group_bwd_input_k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return AM_ERR_LAUNCH;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(linear_group_bwd_input_k, dim3(am_cdiv(kmax_in, 64), am_cdiv(M, MB), count), dim3(1024), lds, ST(stream), g, M);
+    AM_CHECK_LAUNCH();
+  }
+  if (kmax_w > 0) {
+    hipLaunchKernelGGL(linear_group_bwd_weight_k, dim3(am_cdiv(kmax_w, 256), nmax_w, count), dim3(256), 0, ST(stream), g, M);
+    AM_CHECK_LAUNCH();
+  }
+  return AM_OK;
+}
+
+extern "C" int am_moe_tail_layernorm_fwd(const am_tail_layernorm* group, int count, int M, am_stream_t stream) {
+  if (!group || count < 1 || count > AM_TAIL_MAX_GROUP || M < 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  LnGroup g;
+  for (int i = 0; i < count; ++i) {
+    const am_tail_layernorm& d = group[i];
+    if (!d.x || !d.gamma || !d.beta || !d.y || !d.mean || !d.rstd || d.D <= 0) return AM_ERR_ARG;
+    g.p[i] = d;
+  }
+  hipLaunchKernelGGL(layernorm_group_fwd_k, dim3(am_cdiv(M, 4), 1, count), dim3(256), 0, ST(stream), g, M);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_moe_tail_layernorm_bwd(const am_tail_layernorm* group, int count, int M, am_stream_t stream) {
+  if (!group || count < 1 || count > AM_TAIL_MAX_GROUP || M < 0) return AM_ERR_ARG;
+  if (M == 0) return AM_OK;
+  LnGroup g;
+  int dmax = 0;
+  for (int i = 0; i < count; ++i) {
+    const am_tail_layernorm& d = group[i];
+    if (!d.dy || !d.x || !d.gamma || !d.mean || !d.rstd || d.D <= 0) return AM_ERR_ARG;
+    g.p[i] = d;
+    dmax = d.D > dmax ? d.D : dmax;
+  }
+  const int gx = am_cdiv(M, 4) > am_cdiv(dmax, 256) ? am_cdiv(M, 4) : am_cdiv(dmax, 256);
+  hipLaunchKernelGGL(layernorm_group_bwd_k, dim3(gx, 2, count), dim3(256), 0, ST(stream), g, M);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -24,6 +24,7 @@ AM_TUNE_RING = 0
 AM_TUNE_RING128_MIN_TILES = 1
 AM_TUNE_WGRAD_RING = 2
 AM_TUNE_WGRAD_MAX_SLABS = 3
+AM_TUNE_RING_SHORT_K = 4
 
 _ERR = {-1: "AM_ERR_ARG (bad argument)", -2: "AM_ERR_LAUNCH (HIP runtime refused the launch)",
         -3: "AM_ERR_UNSUPPORTED (shape/dtype not built)"}
@@ -36,6 +37,22 @@ class ConvGeom(ctypes.Structure):
         "iys", "ixs", "ntaps", "krun", "pix_shift", "N")] + [("dy", ctypes.c_int16 * AM_MAX_TAPS),
                                                                ("dx", ctypes.c_int16 * AM_MAX_TAPS),
                                                                ("osplit", ctypes.c_int32), ("osplit_stride", ctypes.c_int32)]
+
+
+AM_TAIL_MAX_GROUP = 8
+
+
+class TailLinear(ctypes.Structure):
+    """am_tail_linear of include/automoe_hip.h."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("x", "W", "bias", "y", "dy", "yact", "dx", "dW", "dbias")]
+                + [(n, ctypes.c_int32) for n in ("ldx", "ldy", "lddy", "ldya", "lddx", "N", "K", "relu", "dx_accumulate")]
+                + [("drop_p", ctypes.c_float), ("gscale", ctypes.c_float), ("seed", ctypes.c_uint64)])
+
+
+class TailLayerNorm(ctypes.Structure):
+    """am_tail_layernorm of include/automoe_hip.h."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("x", "gamma", "beta", "y", "mean", "rstd", "dy", "dx", "dgamma", "dbeta")]
+                + [(n, ctypes.c_int32) for n in ("ldx", "ldy", "lddy", "lddx", "D")] + [("eps", ctypes.c_float)])
 
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
@@ -97,7 +114,8 @@ class _Lib:
             else:
                 setattr(self, name, self._checked(name, fn))
         # A/B builds and CI legs pin kernels without code changes: AUTOMOE_TUNE_<KEY>=<int> (keys of am_set_tuning)
-        for key, idx in (("RING", AM_TUNE_RING), ("RING128_MIN_TILES", AM_TUNE_RING128_MIN_TILES), ("WGRAD_RING", AM_TUNE_WGRAD_RING), ("WGRAD_MAX_SLABS", AM_TUNE_WGRAD_MAX_SLABS)):
+        for key, idx in (("RING", AM_TUNE_RING), ("RING128_MIN_TILES", AM_TUNE_RING128_MIN_TILES), ("WGRAD_RING", AM_TUNE_WGRAD_RING), ("WGRAD_MAX_SLABS", AM_TUNE_WGRAD_MAX_SLABS),
+                         ("RING_SHORT_K", AM_TUNE_RING_SHORT_K)):
             v = os.environ.get("AUTOMOE_TUNE_" + key)
             if v is not None:
                 self.am_set_tuning(idx, int(v))
@@ -105,6 +123,8 @@ class _Lib:
     @staticmethod
     def _checked(name, fn):
         def call(*args):
+            if CALL_COUNTS is not None:
+                CALL_COUNTS[name] = CALL_COUNTS.get(name, 0) + 1
             rc = fn(*args)
             if rc != 0:
                 raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
@@ -113,6 +133,7 @@ class _Lib:
 
 
 _LIB = None
+CALL_COUNTS = None  # set to a dict to count ABI calls per entry point (bench.py: launches of the MoE tail per step)
 
 
 def get() -> _Lib:

@@ -317,6 +317,155 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class GroupedLinear(torch.autograd.Function):
+    """G independent layers y_i = dropout_p(relu?(x_i W_i^T + b_i)) in ONE launch (am_moe_tail_linear_fwd); backward in two
+    (input gradients of all members, parameter gradients of all members).  The reference's Linear -> ReLU -> Dropout triples of
+    the MoE tail (expert_extractors.py:30-34, context_features.py:143-149, gating_network.py:13-20,38-44, trajectory_head.py:44-53)
+    run as the epilogue of the Linear; the dropout mask is never stored (y == 0 <=> dropped or rectified).
+    apply(spec, x_0, W_0, b_0, x_1, W_1, b_1, ...) -> (y_0, y_1, ...); spec = [(relu, drop_p), ...] (drop_p 0 in eval mode)."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        global _DROPOUT_CALLS
+        from . import lib as _lib
+        G = len(spec)
+        assert len(tensors) == 3 * G and 1 <= G <= _lib.AM_TAIL_MAX_GROUP
+        xs = [tensors[3 * i].contiguous() for i in range(G)]
+        Ws, bs = [tensors[3 * i + 1] for i in range(G)], [tensors[3 * i + 2] for i in range(G)]
+        require_hip(xs[0], "linear input")
+        M = xs[0].shape[0]
+        ys = [torch.empty((M, W.shape[0]), dtype=torch.float32, device=xs[0].device) for W in Ws]
+        arr = (_lib.TailLinear * G)()
+        seeds = []
+        for i, (relu, p_drop) in enumerate(spec):
+            assert xs[i].shape == (M, Ws[i].shape[1]) and xs[i].dtype == torch.float32
+            d = arr[i]
+            d.x, d.W, d.bias, d.y = ptr(xs[i]), ptr(Ws[i]), ptr(bs[i]), ptr(ys[i])
+            d.ldx, d.ldy, d.N, d.K, d.relu = xs[i].shape[1], ys[i].shape[1], Ws[i].shape[0], Ws[i].shape[1], int(relu)
+            d.drop_p = float(p_drop)
+            if p_drop > 0.0:
+                _DROPOUT_CALLS += 1
+                d.seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROPOUT_CALLS * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            seeds.append(int(d.seed))
+        step = _runtime().step_counter(xs[0].device) if any(p_ > 0.0 for _, p_ in spec) else None
+        _L().am_moe_tail_linear_fwd(arr, G, M, ptr(step), stream())
+        ctx.spec, ctx.G, ctx.M = list(spec), G, M
+        ctx.params = [(Ws[i], bs[i]) for i in range(G)]
+        ctx.save_for_backward(*xs, *Ws, *[ys[i] if (spec[i][0] or spec[i][1] > 0.0) else xs[i].new_empty(0) for i in range(G)])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import lib as _lib
+        G, M = ctx.G, ctx.M
+        saved = ctx.saved_tensors
+        xs, Ws, yacts = saved[:G], saved[G:2 * G], saved[2 * G:]
+        arr = (_lib.TailLinear * G)()
+        grads = [None] * (3 * G)
+        keep = []  # tensors the launches read: alive until this function returns (same stream: the allocator orders reuse)
+        direct_done = []
+        n_active = 0
+        for i in range(G):
+            relu, p_drop = ctx.spec[i]
+            d = arr[i]
+            N, K = Ws[i].shape
+            dy = dys[i]
+            if dy is None:
+                dy = torch.zeros((M, N), dtype=torch.float32, device=xs[i].device)
+            dy = dy.contiguous()
+            keep.append(dy)
+            d.x, d.W, d.dy = ptr(xs[i]), ptr(Ws[i]), ptr(dy)
+            d.ldx, d.lddy, d.N, d.K = K, N, N, K
+            d.gscale = 1.0 / (1.0 - p_drop) if p_drop > 0.0 else 1.0
+            if yacts[i].numel():
+                d.yact, d.ldya = ptr(yacts[i]), N
+            if ctx.needs_input_grad[1 + 3 * i]:
+                dx = torch.empty_like(xs[i])
+                d.dx, d.lddx, d.dx_accumulate = ptr(dx), K, 0
+                grads[3 * i] = dx
+            Wp, bp = ctx.params[i]
+            need_w = ctx.needs_input_grad[2 + 3 * i]
+            need_b = bp is not None and ctx.needs_input_grad[3 + 3 * i]
+            if need_w or need_b:
+                if _runtime().direct_grads() and need_w and _grad_ready(Wp) and (bp is None or (need_b and _grad_ready(bp))):
+                    d.dW, d.dbias = ptr(Wp.grad), ptr(bp.grad) if bp is not None else None
+                    direct_done.append((Wp, bp))
+                else:
+                    dW = torch.zeros_like(Ws[i])
+                    db = torch.zeros(N, dtype=torch.float32, device=Ws[i].device) if bp is not None else None
+                    d.dW, d.dbias = ptr(dW), ptr(db)
+                    grads[3 * i + 1], grads[3 * i + 2] = dW, db
+            n_active += 1
+        _L().am_moe_tail_linear_bwd(arr, G, M, stream())
+        for Wp, bp in direct_done:
+            _runtime().grad_ready(Wp, bp)
+        return (None, *grads)
+
+
+class GroupedLayerNorm(torch.autograd.Function):
+    """G independent LayerNorms in one launch (am_moe_tail_layernorm_fwd); backward (input + parameter gradients) in one.
+    apply(eps_list, x_0, gamma_0, beta_0, x_1, ...) -> (y_0, y_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, eps_list, *tensors):
+        from . import lib as _lib
+        G = len(eps_list)
+        assert len(tensors) == 3 * G and 1 <= G <= _lib.AM_TAIL_MAX_GROUP
+        xs = [tensors[3 * i].contiguous() for i in range(G)]
+        gs, bs = [tensors[3 * i + 1] for i in range(G)], [tensors[3 * i + 2] for i in range(G)]
+        require_hip(xs[0], "layernorm input")
+        M = xs[0].shape[0]
+        ys = [torch.empty_like(x) for x in xs]
+        stats = torch.empty((G, 2, M), dtype=torch.float32, device=xs[0].device)
+        arr = (_lib.TailLayerNorm * G)()
+        for i in range(G):
+            d = arr[i]
+            D = xs[i].shape[1]
+            d.x, d.gamma, d.beta, d.y, d.mean, d.rstd = ptr(xs[i]), ptr(gs[i]), ptr(bs[i]), ptr(ys[i]), ptr(stats[i, 0]), ptr(stats[i, 1])
+            d.ldx, d.ldy, d.D, d.eps = D, D, D, float(eps_list[i])
+        _L().am_moe_tail_layernorm_fwd(arr, G, M, stream())
+        ctx.G, ctx.M, ctx.eps = G, M, list(eps_list)
+        ctx.params = [(gs[i], bs[i]) for i in range(G)]
+        ctx.save_for_backward(stats, *xs, *gs)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import lib as _lib
+        G, M = ctx.G, ctx.M
+        stats, *rest = ctx.saved_tensors
+        xs, gs = rest[:G], rest[G:]
+        arr = (_lib.TailLayerNorm * G)()
+        grads = [None] * (3 * G)
+        keep, direct_done = [], []
+        for i in range(G):
+            d = arr[i]
+            D = xs[i].shape[1]
+            dy = dys[i] if dys[i] is not None else torch.zeros_like(xs[i])
+            dy = dy.contiguous()
+            keep.append(dy)
+            d.x, d.gamma, d.mean, d.rstd, d.dy = ptr(xs[i]), ptr(gs[i]), ptr(stats[i, 0]), ptr(stats[i, 1]), ptr(dy)
+            d.ldx, d.lddy, d.D, d.eps = D, D, D, float(ctx.eps[i])
+            if ctx.needs_input_grad[1 + 3 * i]:
+                dx = torch.empty_like(xs[i])
+                d.dx, d.lddx = ptr(dx), D
+                grads[3 * i] = dx
+            gp, bp = ctx.params[i]
+            if ctx.needs_input_grad[2 + 3 * i] or ctx.needs_input_grad[3 + 3 * i]:
+                if (_runtime().direct_grads() and ctx.needs_input_grad[2 + 3 * i] and ctx.needs_input_grad[3 + 3 * i]
+                        and _grad_ready(gp) and _grad_ready(bp)):
+                    d.dgamma, d.dbeta = ptr(gp.grad), ptr(bp.grad)
+                    direct_done.append((gp, bp))
+                else:
+                    dg, db = torch.zeros_like(gs[i]), torch.zeros_like(gs[i])
+                    d.dgamma, d.dbeta = ptr(dg), ptr(db)
+                    grads[3 * i + 1], grads[3 * i + 2] = dg, db
+        _L().am_moe_tail_layernorm_bwd(arr, G, M, stream())
+        for gp, bp in direct_done:
+            _runtime().grad_ready(gp, bp)
+        return (None, *grads)
+
+
 _DROPOUT_CALLS = 0
 
 

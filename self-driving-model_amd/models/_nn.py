@@ -117,3 +117,31 @@ class MLPSequential(nn.Sequential):
                 x = m(x)
                 i += 1
         return x
+
+
+# ---- grouped launches for the parallel branches of the MoE tail (hip/ops.py GroupedLinear / GroupedLayerNorm) --------------
+def grouped_linear(layers, inputs, relu, dropouts=None):
+    """[act(layer_i(x_i))] for independent nn.Linear layers in ONE launch; `dropouts` (optional, per layer: a Dropout module or
+    None) is the Dropout that follows Linear -> ReLU in the reference's Sequential, fused into the same epilogue when it is
+    active (training, p > 0)."""
+    dropouts = dropouts or [None] * len(layers)
+    spec, args = [], []
+    for layer, x, dr in zip(layers, inputs, dropouts):
+        p = float(dr.p) if (dr is not None and dr.training and dr.p > 0.0) else 0.0
+        spec.append((bool(relu), p))
+        args += [x, layer.weight, layer.bias]
+    return list(hops.GroupedLinear.apply(spec, *args))
+
+
+def grouped_layernorm(norms, inputs):
+    args = []
+    for ln, x in zip(norms, inputs):
+        args += [x, ln.weight, ln.bias]
+    return list(hops.GroupedLayerNorm.apply([ln.eps for ln in norms], *args))
+
+
+def mlp5(seq):
+    """(Linear, Dropout, Linear, LayerNorm) of a reference `Linear, ReLU, Dropout, Linear, LayerNorm` tail of a Sequential."""
+    mods = list(seq)[-5:]
+    assert isinstance(mods[0], Linear) and isinstance(mods[2], nn.Dropout) and isinstance(mods[3], Linear) and isinstance(mods[4], nn.LayerNorm)
+    return mods[0], mods[2], mods[3], mods[4]

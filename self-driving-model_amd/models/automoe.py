@@ -23,6 +23,7 @@ from .experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExper
 from .experts.expert_extractors import create_expert_extractors
 from .gating.gating_network import GatingNetwork
 from .policy.trajectory_head import TrajectoryPolicy
+from ._nn import grouped_layernorm, grouped_linear, mlp5
 
 
 def _last_step(t: torch.Tensor) -> torch.Tensor:
@@ -57,6 +58,9 @@ class AutoMoE(nn.Module):
         self._side_stream = None
         self._expert_streams = []
         self.parallel_experts = os.environ.get("AUTOMOE_PARALLEL_EXPERTS", "1") != "0"
+        # the parallel branches of the MoE tail (per-expert extractor / processor MLPs, context encoders, policy heads) as grouped
+        # launches: ~15 launches forward instead of ~46 (hip/ops.py GroupedLinear / GroupedLayerNorm); off = one launch per layer
+        self.group_tail = os.environ.get("AUTOMOE_GROUP_TAIL", "1") != "0"
         self.to(device)
 
     def _create_experts(self) -> nn.ModuleList:
@@ -97,7 +101,8 @@ class AutoMoE(nn.Module):
                                 context_dim=self.gating_config.get("processed_dim", 256),
                                 backbone_dim=self.policy_config.get("backbone_dim", 512))
 
-    def _extract_context_features(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _vehicle_state(self, batch: Dict[str, torch.Tensor]):
+        """(speed, steering, throttle, brake) at the last step, [B,1] each (reference automoe.py:101-135)."""
         if self.context_config.get("type", "simple") != "simple":
             raise ValueError("only the 'simple' context extractor is on the accelerated path")
         speed = batch["speed"]
@@ -109,7 +114,40 @@ class AutoMoE(nn.Module):
             steering = torch.zeros(bsz, 1, device=device)
             throttle = torch.zeros(bsz, 1, device=device)
             brake = torch.zeros(bsz, 1, device=device)
-        return self.context_extractor(speed_in, steering, throttle, brake)
+        return speed_in, steering, throttle, brake
+
+    def _extract_context_features(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        return self.context_extractor(*self._vehicle_state(batch))
+
+    def _tail_grouped(self, mlp_inputs: List[torch.Tensor], batch: Dict[str, torch.Tensor]):
+        """Extractor MLPs + context extractor + GatingNetwork.forward (gating_network.py:122-175) with every stage's independent
+        branches in one launch.  Same modules, same arithmetic per layer as the ungrouped path (a Linear -> ReLU -> Dropout triple
+        is one epilogue; its mask comes from the same counter-based generator).  Returns (context_features, gating_output)."""
+        gn = self.gating_network
+        E = len(mlp_inputs)
+        ext = [mlp5(ex.feature_extractor) for ex in self.expert_extractors.extractors]
+        cl1, cdr, cl2, cln = mlp5(self.context_extractor.encoder)
+        vehicle_state = torch.cat(self._vehicle_state(batch), dim=-1).float()
+        h = grouped_linear([e[0] for e in ext] + [cl1], mlp_inputs + [vehicle_state], True, [e[1] for e in ext] + [cdr])
+        h = grouped_linear([e[2] for e in ext] + [cl2], h, False)
+        h = grouped_layernorm([e[3] for e in ext] + [cln], h)
+        feats, context_features = h[:E], h[E]
+        proc = [mlp5(p.processor) for p in gn.expert_processors]
+        ce = list(gn.context_encoder.context_encoder)  # Linear, ReLU, Dropout, Linear, ReLU, Dropout
+        h = grouped_linear([p[0] for p in proc] + [ce[0]], feats + [context_features], True, [p[1] for p in proc] + [ce[2]])
+        # second layers: the processors' have no activation, the context encoder's has ReLU + Dropout -> two groups by epilogue
+        hp = grouped_linear([p[2] for p in proc], h[:E], False)
+        (ctx_enc,) = grouped_linear([ce[3]], [h[E]], True, [ce[5]])
+        processed = grouped_layernorm([p[3] for p in proc], hp)
+        gate_input = torch.cat([ctx_enc] + processed, dim=1)
+        g1, gdr, g2 = gn.gate_network[0], gn.gate_network[2], gn.gate_network[3]
+        (hid,) = grouped_linear([g1], [gate_input], True, [gdr])
+        (gate_logits,) = grouped_linear([g2], [hid], False)
+        apply_topk = (gn.top_k > 0) and (gn.training or gn.apply_topk_at_eval)
+        gate_weights, combined = gn._gate(gate_logits, processed, apply_topk)
+        (out,) = grouped_linear([gn.output_projection], [combined], False)
+        return context_features, {"combined_output": out, "expert_weights": gate_weights, "processed_expert_outputs": processed,
+                                  "gate_logits": gate_logits}
 
     def _run_experts(self, batch: Dict[str, torch.Tensor], nhwc: torch.Tensor) -> List:
         outs = []
@@ -172,6 +210,8 @@ class AutoMoE(nn.Module):
             pend, outs = self._run_expert_trunks(batch, nhwc)
         if fork is not None:
             fork()
+        if self.group_tail:  # the extractor MLPs run grouped with the rest of the tail: hand back their [B, C] inputs
+            return outs, [t if pooled else extractor.pre_mlp(t) for extractor, (t, pooled) in zip(self.expert_extractors.extractors, pend)]
         feats = []
         for extractor, (t, pooled) in zip(self.expert_extractors.extractors, pend):
             feats.append(extractor.feature_extractor(t, start=2) if pooled else extractor(t))  # pooled: skip pool + flatten
@@ -195,7 +235,8 @@ class AutoMoE(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor], expert_cache: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
         runtime.begin_step(batch["image"].device)
-        context_features = self._extract_context_features(batch)
+        grouped = self.group_tail and self.fuse_expert_pooling and batch["image"].is_cuda
+        context_features = None if grouped else self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
         # The policy backbone (a conv stack on the image) does not depend on the experts; the extractor / gating MLPs
         # that follow them are dozens of launch-latency-bound kernels on [B, <=512] tensors.  With overlap_policy_backbone
@@ -218,7 +259,10 @@ class AutoMoE(nn.Module):
         else:
             expert_outputs = self._run_experts(batch, nhwc)
             expert_features = self.expert_extractors.extract_features(expert_outputs)
-        gating_output = self.gating_network(expert_features, context_features)
+        if grouped:
+            context_features, gating_output = self._tail_grouped(expert_features, batch)
+        else:
+            gating_output = self.gating_network(expert_features, context_features)
         if "feat" in side:
             torch.cuda.current_stream().wait_stream(self._side_stream)
             side["feat"].record_stream(torch.cuda.current_stream())

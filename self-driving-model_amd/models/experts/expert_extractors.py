@@ -28,6 +28,11 @@ class DetectionExpertExtractor(ExpertOutputExtractor):
         self.num_classes = num_classes
         self.feature_extractor = _mlp(num_classes + 4, output_dim)
 
+    def pre_mlp(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """[B, C] input of the extractor MLP (everything in front of its first Linear)."""
+        combined = torch.cat([expert_output["class_logits"], expert_output["bbox_deltas"]], dim=1)
+        return self.feature_extractor[1](self.feature_extractor[0](combined))
+
     def forward(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
         combined = torch.cat([expert_output["class_logits"], expert_output["bbox_deltas"]], dim=1)
         return self.feature_extractor(combined)
@@ -38,6 +43,9 @@ class SegmentationExpertExtractor(ExpertOutputExtractor):
         super().__init__(output_dim)
         self.num_classes = num_classes
         self.feature_extractor = _mlp(num_classes, output_dim)
+
+    def pre_mlp(self, expert_output: torch.Tensor) -> torch.Tensor:
+        return self.feature_extractor[1](self.feature_extractor[0](expert_output))
 
     def forward(self, expert_output: torch.Tensor) -> torch.Tensor:
         return self.feature_extractor(expert_output)
@@ -57,9 +65,12 @@ class NuScenesExpertExtractor(ExpertOutputExtractor):
         self.feature_extractor = MLPSequential(Linear(num_queries * (num_classes + bbox_dim), 512), ReLU(), Dropout(0.1),
                                                Linear(512, output_dim), LayerNorm(output_dim))
 
-    def forward(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def pre_mlp(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
         combined = torch.cat([expert_output["class_logits"], expert_output["bbox_preds"]], dim=-1)
-        return self.feature_extractor(combined.view(combined.size(0), -1))
+        return combined.view(combined.size(0), -1)
+
+    def forward(self, expert_output: Dict[str, torch.Tensor]) -> torch.Tensor:
+        return self.feature_extractor(self.pre_mlp(expert_output))
 
 
 class ExpertOutputManager(nn.Module):

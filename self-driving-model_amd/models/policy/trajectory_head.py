@@ -7,7 +7,7 @@ import torch.nn as nn
 from ... import runtime
 from ...hip import conv as hconv
 from ...hip import ops as hops
-from .._nn import BatchNorm2d, Conv2d, Linear, MLPSequential, ReLU, conv_bn_act
+from .._nn import BatchNorm2d, Conv2d, Linear, MLPSequential, ReLU, conv_bn_act, grouped_linear
 
 
 class EasyBackbone(nn.Module):
@@ -46,12 +46,19 @@ class TrajectoryPolicy(nn.Module):
                                      Linear(hidden, horizon * 2))
         self.head_spd = MLPSequential(Linear(head_in_dim, hidden), ReLU(inplace=True), Linear(hidden, hidden), ReLU(inplace=True),
                                       Linear(hidden, horizon))
+        self.group_heads = True  # tests flip this to compare with one launch per layer and head
 
     def forward(self, image: torch.Tensor, context: Optional[torch.Tensor] = None,
                 nhwc_input: Optional[torch.Tensor] = None, backbone_feat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         # backbone_feat: the backbone's output when the caller already ran it (AutoMoE overlaps it with the gating MLPs)
         feat = backbone_feat if backbone_feat is not None else self.backbone(image, nhwc_input=nhwc_input)
         x = torch.cat([feat, context], dim=1) if context is not None else feat
-        wp = self.head_wp(x).view(-1, self.horizon, 2)
-        spd = self.head_spd(x).view(-1, self.horizon)
-        return {"waypoints": wp, "speed": spd}
+        if self.group_heads and x.is_cuda:
+            # the two heads are independent 3-layer MLPs on the same input: each layer of both in one launch
+            h = [x, x]
+            for i in (0, 2, 4):
+                h = grouped_linear([self.head_wp[i], self.head_spd[i]], h, relu=(i < 4))
+            wp, spd = h
+        else:
+            wp, spd = self.head_wp(x), self.head_spd(x)
+        return {"waypoints": wp.view(-1, self.horizon, 2), "speed": spd.view(-1, self.horizon)}

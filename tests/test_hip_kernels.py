@@ -712,7 +712,7 @@ def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
     assert rel_err(outs[0], outs[1]) < 1e-3
 
 
-@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 96, 100, True), (128, 256, 3, 2, 1, 2, 370, 361, False), (256, 512, 1, 2, 0, 8, 128, 160, False)])
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 96, 100, True), (128, 256, 3, 2, 1, 2, 370, 361, False), (64, 256, 3, 1, 1, 4, 128, 128, False)])
 def test_ring_kernel_generations_agree(case):
     """conv_ring16_k (AM_TUNE_RING 1 block issue / 2 spread / 3 by wave age) against conv_ring_k (0) through am_set_tuning: the
     same products summed in fp32 in another order -- outputs equal after f16 rounding up to one ulp on a few elements,
@@ -817,3 +817,33 @@ def test_wgrad_workspace_form_vs_torch_and_atomic_form(case):
         runtime.set_direct_grads(False)
     # (v + 2) - 2 in fp32 costs an ulp of |v| <= 64; the atomic single-slab mode adds its own summation-order noise
     assert rel_err(wparam.grad - 2.0, outs[0]) < 2e-6, rel_err(wparam.grad - 2.0, outs[0])
+
+
+@pytest.mark.parametrize("case", [(128, 256, 16, 128, 160), (256, 512, 8, 128, 160)])
+def test_shortcut_conv_takes_the_two_workgroup_tile(case):
+    """1x1 / stride-2 shortcut convolutions (torchvision BasicBlock.downsample, K = Cin: 4 or 8 K-steps) are all prologue and
+    epilogue: AM_TUNE_RING_SHORT_K sends them to conv_ring_k<256,128> (two workgroups per CU) although N >= 256; results equal
+    the 256x256 ring tile's bit for bit (same products, same fp32 order per output) and torch's."""
+    from self_driving_model_amd.hip import conv as hc
+    cin, cout, B, H, W = case
+    L = hc._L()
+    g = torch.Generator().manual_seed(cin)
+    x4 = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).half().float()
+    s = hc.ConvSpec(cin, cout, 1, 2, 0)
+    geom = hc.fwd_geom(s, B, H, W, cin, cout, 2)
+    wp = hc.pack_fwd(w.to(_dev()), s, torch.float16)
+    xd = nhwc(x4, torch.float16)
+    outs = {}
+    old = L.am_get_tuning(4)
+    try:
+        for sk, name in ((8, "conv_ring_k<256,128>"), (0, "conv_ring16_k<256,256>")):
+            L.am_set_tuning(4, sk)
+            y = torch.zeros(B, geom.OH, geom.OW, cout, dtype=torch.float16, device=_dev())
+            hc.conv_gemm(geom, xd, wp, None, False, y, None)
+            launched_kernel(name, what=f"shortcut conv {case} short_k={sk}")
+            outs[sk] = y.float().cpu()
+    finally:
+        L.am_set_tuning(4, old)
+    assert rel_err(outs[8], outs[0]) < 1e-4
+    assert rel_err(nchw(outs[8], cout), F.conv2d(x4, w, stride=2)) < 2e-3

@@ -1396,3 +1396,56 @@ def test_capture_survives_a_caller_that_keeps_every_loss():
         assert tr._graph is not None and all(t.grad_fn is None for t in kept[5:])
     torch.cuda.synchronize()
     assert all(np.isfinite(float(t)) for t in kept[5:])
+
+
+def test_grouped_moe_tail_matches_one_launch_per_layer():
+    """The MoE tail with every stage's independent branches in one launch (AutoMoE.group_tail, TrajectoryPolicy.group_heads:
+    am_moe_tail_linear_* / am_moe_tail_layernorm_*) against one launch per layer: same modules, same per-layer arithmetic --
+    outputs, loss and every parameter gradient agree to fp32 rounding -- in far fewer ABI calls; with dropout active the fused
+    Linear -> ReLU -> Dropout epilogue must drop about p of the activations, rescale the rest and still train."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import lib as hlib
+    from self_driving_model_amd.training.train_gating_network import compute_gating_losses
+    hip, _ = _automoe_pair(250)
+    hip.freeze_experts()
+    hip.train()
+    hip.fuse_expert_pooling = True
+    for d in hip.modules():
+        if isinstance(d, torch.nn.Dropout):
+            d.p = 0.0
+    batch = {k: v.to(_dev()) for k, v in _batch(3, 64, 96, 260).items()}
+    res, calls = {}, {}
+    with runtime.precision(torch.float32):
+        for grouped in (False, True):
+            hip.group_tail = hip.policy_head.group_heads = grouped
+            hip.zero_grad(set_to_none=True)
+            hlib.CALL_COUNTS = {}
+            o = hip(batch)
+            loss = compute_gating_losses(o, batch["waypoints"], batch["speed"], {})["total_loss"]
+            loss.backward()
+            tail = {k: v for k, v in hlib.CALL_COUNTS.items() if k.startswith(("am_linear", "am_layernorm", "am_moe_tail", "am_gate", "am_dropout"))}
+            hlib.CALL_COUNTS = None
+            calls[grouped] = sum(tail.values())
+            res[grouped] = ({k: o[k].detach().clone() for k in ("waypoints", "speed_seq", "expert_weights", "gate_logits", "combined_features", "context_features")},
+                            float(loss), {n: p.grad.detach().clone() for n, p in hip.named_parameters() if p.grad is not None})
+    assert calls[True] <= 0.45 * calls[False], calls  # ~40 ABI calls instead of ~110 for forward + backward
+    for k, v in res[False][0].items():
+        close(res[True][0][k], v, rtol=1e-5, atol=1e-6, what=k)
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
+    assert set(res[True][2]) == set(res[False][2])
+    for n, g in res[False][2].items():
+        close(res[True][2][n], g, rtol=1e-4, atol=1e-6, what=n)
+    # dropout active (p = 0.5 everywhere it exists): statistics of the fused epilogue, and the step still runs end to end
+    from self_driving_model_amd.models._nn import grouped_linear
+    lin = hip.gating_network.expert_processors[0].processor[0]
+    dr = torch.nn.Dropout(0.5).train()
+    x = torch.randn(64, 256, device=_dev())
+    with runtime.precision(torch.float32):
+        (y,) = grouped_linear([lin], [x], True, [dr])
+        (y0,) = grouped_linear([lin], [x], True, [None])
+    kept = (y != 0)
+    act = (y0 > 0)
+    frac = float(kept.sum()) / max(1.0, float(act.sum()))
+    assert 0.42 < frac < 0.58, frac
+    close(y[kept], 2.0 * y0[kept], rtol=1e-6, atol=1e-7, what="kept activations are rescaled by 1 / (1 - p)")
+    assert not bool((kept & ~act).any())
