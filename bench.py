@@ -183,8 +183,15 @@ def main():
         saved_par = (model.parallel_experts, model.overlap_policy_backbone)
         model.parallel_experts = model.overlap_policy_backbone = False
         hconv.TIMER = hconv.KernelTimer()
+        from self_driving_model_amd.hip import lib as hlib
+        hlib.CALL_COUNTS = {}
         for _ in range(2):
             run()
+        calls, hlib.CALL_COUNTS = hlib.CALL_COUNTS, None
+        tail_prefixes = ("am_linear", "am_layernorm", "am_moe_tail", "am_gate", "am_dropout")
+        out["moe_tail"] = {"grouped": bool(model.group_tail),
+                           "abi_calls_per_step_fwd_bwd": sum(v for k, v in calls.items() if k.startswith(tail_prefixes)) // 2,
+                           "all_abi_calls_per_step": sum(calls.values()) // 2}
         summ = hconv.TIMER.summary()
         per_kernel = hconv.TIMER.summary(by="kernel")
         hconv.TIMER = None

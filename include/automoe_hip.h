@@ -106,8 +106,8 @@ int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const fl
 
 /* Diagnostic (bench.py roofline leg, kernel tests): which kernel the last am_conv_gemm / am_conv_first_fused / am_conv_wgrad call
  * made by the CALLING HOST THREAD launched (thread-local record).
- * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 conv3x3_c64n64_wreg_k,
- * 5 conv3x3_c64n64_k, 6 conv_gemm2_k, 7 conv_gemm3_k, 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
+ * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 (retired), 5 conv3x3_c64n64_k,
+ * 6 conv_gemm2_k, 7 (retired), 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
  * 11 conv_ring16_k<256,256>, 12 conv_ring16_k<256,128>, 13 wgrad_ring_k, 14 conv_wgrad_k (register-staged), 15 conv_s2d_wgrad_k. */
 int am_conv_last_variant(void);
 

@@ -342,11 +342,7 @@ int launch_conv(const ConvKParams& p, hipStream_t s) {
   return p.g.pix_shift < 31 ? launch_conv_m<T, BM, BN, WM, WN, true>(p, s) : launch_conv_m<T, BM, BN, WM, WN, false>(p, s);
 }
 
-static int big_tile_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("AM_CONV_BIGTILE"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static int big_tile_mode() { return 1; }
 
 template <typename T>
 int dispatch_conv(const ConvKParams& p, hipStream_t s) {
@@ -615,16 +611,8 @@ int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* 
                     const float* shift, int relu, void* y, double* stats, hipStream_t s);  // conv_s2d.hip
 int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
                               double* stats, hipStream_t s);  // conv_patch3.hip
-int am_conv3x3_c64n64_wreg_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
-                               double* stats, hipStream_t s);  // conv_patch2.hip
 int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                           hipStream_t s);  // conv_patch.hip
-
-static bool use_v1_only() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("AM_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
 
 thread_local int g_am_conv_variant = AM_CV_NONE;
 
@@ -679,24 +667,18 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->osplit > 0)  // split output rows (fused stride-2 dgrad): ring kernels only
     return dtype == AM_F16 && bias == nullptr && !relu && stats == nullptr ? am_conv_ring_f16(g, x, w, bias, relu, y, stats, s) : AM_ERR_UNSUPPORTED;
-  if (dtype == AM_F16 && !use_v1_only()) {
+  if (dtype == AM_F16) {
     // 3-channel first layers on the space-to-depth image: weights-stationary patch kernel
     rc = am_conv_s2d_f16(g, 0, x, w, bias, nullptr, nullptr, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
-    static int wreg = -1;
-    if (wreg < 0) { const char* e = getenv("AM_PATCH_WREG"); wreg = e ? atoi(e) : 2; }
-    if (wreg) {
-      rc = wreg == 2 ? am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, y, stats, s) : am_conv3x3_c64n64_wreg_f16(g, x, w, bias, relu, y, stats, s);
-      if (rc != AM_ERR_UNSUPPORTED) return rc;
-    }
-    rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);
+    rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, y, stats, s);
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+    rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);  // the same layers with a bias / ReLU epilogue or tensors >= 1 GiB
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads
     // into 64 channels) stays on the register-staged kernel
-    static int ring_all = -1;
-    if (ring_all < 0) { const char* e = getenv("AM_CONV_RING_ALL"); ring_all = e ? atoi(e) : 1; }
-    if ((long long)p.M <= 65536 || g->N >= 256 || (ring_all && g->N > 64)) {
+    if ((long long)p.M <= 65536 || g->N > 64) {
       rc = am_conv_gemm2_f16(g, x, w, bias, relu, y, stats, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
@@ -718,9 +700,7 @@ static int wgrad_dispatch(const am_conv_geom* g, int dtype, const void* x, const
   p.Ktot = g->ntaps * g->krun;
   p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
   if (dtype == AM_F16) {
-    static int s2dw = -1;
-    if (s2dw < 0) { const char* e = getenv("AM_WGRAD_S2D"); s2dw = e ? atoi(e) : 1; }
-    if (s2dw && g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip); atomic form only
+    if (g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip); atomic form only
       if (plan_only || ws) return plan_only ? 0 : AM_ERR_UNSUPPORTED;
       const int rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;

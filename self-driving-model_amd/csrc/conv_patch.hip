@@ -281,7 +281,7 @@ int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, c
   p.tiles_y = am_cdiv(g->IH, TH);
   p.tiles_x = am_cdiv(g->IW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
-  { const char* e = getenv("AM_PATCH_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = 0;
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {

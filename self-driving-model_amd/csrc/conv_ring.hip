@@ -399,11 +399,9 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   // (a contraction of a few K-steps -- the 1x1 / stride-2 shortcut convolutions -- is all prologue and epilogue: two 256x128
   // workgroups per CU overlap one's epilogue with the other's loads, one 256x256 workgroup cannot)
   if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K)) return launch_ring<256, 256, 2, 4>(p, s);
-  static int n128 = -1;
-  if (n128 < 0) { const char* e = getenv("AM_RING_N128"); n128 = e ? atoi(e) : 0; }
   // 256x128 tiles run two workgroups per CU (72 KiB of LDS each); below one workgroup per CU a lone workgroup still has its CU's
   // matrix pipes to itself, so the ring kernel keeps beating the two-stage kernels down to AM_TUNE_RING128_MIN_TILES tiles
-  if (mt256 * ((g->N + 127) / 128) >= am_tuning(AM_TUNE_RING128_MIN_TILES)) return n128 == 1 ? launch_ring<256, 128, 2, 2>(p, s) : launch_ring<256, 128, 4, 2>(p, s);
+  if (mt256 * ((g->N + 127) / 128) >= am_tuning(AM_TUNE_RING128_MIN_TILES)) return launch_ring<256, 128, 4, 2>(p, s);
   return AM_ERR_UNSUPPORTED;
 }
 

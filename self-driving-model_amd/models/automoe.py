@@ -210,7 +210,7 @@ class AutoMoE(nn.Module):
             pend, outs = self._run_expert_trunks(batch, nhwc)
         if fork is not None:
             fork()
-        if self.group_tail:  # the extractor MLPs run grouped with the rest of the tail: hand back their [B, C] inputs
+        if getattr(self, "_grouped_now", self.group_tail):  # the extractor MLPs run grouped with the rest of the tail: hand back their [B, C] inputs
             return outs, [t if pooled else extractor.pre_mlp(t) for extractor, (t, pooled) in zip(self.expert_extractors.extractors, pend)]
         feats = []
         for extractor, (t, pooled) in zip(self.expert_extractors.extractors, pend):
@@ -235,7 +235,8 @@ class AutoMoE(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor], expert_cache: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
         runtime.begin_step(batch["image"].device)
-        grouped = self.group_tail and self.fuse_expert_pooling and batch["image"].is_cuda
+        # (swallowed expert failures put ready-made zero features in place of expert outputs: that path keeps one launch per layer)
+        grouped = self._grouped_now = self.group_tail and os.environ.get("AUTOMOE_SWALLOW_EXPERT_ERRORS", "0") != "1"
         context_features = None if grouped else self._extract_context_features(batch)
         nhwc = hops.image_to_nhwc(batch["image"], runtime.compute_dtype())  # one read of the image for 4 backbones
         # The policy backbone (a conv stack on the image) does not depend on the experts; the extractor / gating MLPs
@@ -258,7 +259,10 @@ class AutoMoE(nn.Module):
             expert_outputs, expert_features = self._run_experts_fused(batch, nhwc, fork_backbone if overlap else None, expert_cache)
         else:
             expert_outputs = self._run_experts(batch, nhwc)
-            expert_features = self.expert_extractors.extract_features(expert_outputs)
+            if grouped:
+                expert_features = [ex.pre_mlp(o) for ex, o in zip(self.expert_extractors.extractors, expert_outputs)]
+            else:
+                expert_features = self.expert_extractors.extract_features(expert_outputs)
         if grouped:
             context_features, gating_output = self._tail_grouped(expert_features, batch)
         else:

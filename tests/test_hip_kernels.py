@@ -847,3 +847,21 @@ def test_shortcut_conv_takes_the_two_workgroup_tile(case):
         L.am_set_tuning(4, old)
     assert rel_err(outs[8], outs[0]) < 1e-4
     assert rel_err(nchw(outs[8], cout), F.conv2d(x4, w, stride=2)) < 2e-3
+
+
+def test_conv3x3_c64n64_fallback_kernel_with_bias_relu_epilogue():
+    """64 -> 64 3x3 layers WITH a bias / ReLU epilogue (not a BatchNorm trunk layer) are outside the weights-in-registers duo kernel;
+    the LDS-weights patch kernel conv3x3_c64n64_k (conv_patch.hip) takes them: pinned by name, checked against torch."""
+    from self_driving_model_amd.hip import conv as hc
+    B, H, W = 2, 180, 320
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 64, H, W, generator=g).half().float()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
+    b = torch.randn(64, generator=g)
+    yr = F.relu(F.conv2d(x, w, b, padding=1))
+    s = hc.ConvSpec(64, 64, 3, 1, 1)
+    y = torch.zeros(B, H, W, 64, dtype=torch.float16, device=_dev())
+    hc.conv_gemm(hc.fwd_geom(s, B, H, W, 64, 64, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), b.to(_dev()), True, y, None)
+    launched_kernel("conv3x3_c64n64_k", what="c64n64 with bias + relu")
+    torch.cuda.synchronize()
+    close(nchw(y, 64), yr, rtol=3e-3, atol=3e-3)
