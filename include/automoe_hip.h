@@ -9,8 +9,11 @@
  * Conventions
  *   - plain C symbols, raw device pointers + sizes + a hipStream_t (passed as void*); no torch types;
  *   - every call returns int: AM_OK (0) or a negative AM_ERR_* code; nothing throws across the ABI;
- *   - the caller owns every buffer; the library allocates nothing and keeps no global mutable
- *     state, so calls on different streams are independent;
+ *   - the caller owns every buffer (scratch included: am_conv_wgrad_workspace_bytes / am_conv_wgrad_ws); the library
+ *     allocates nothing, and calls on different streams are independent.  What it keeps beyond the call: the process-wide
+ *     tuning table of am_set_tuning() (A/B switches, set before launching; no environment variable is read anywhere), a
+ *     per-host-thread record of the last conv kernel launched (am_conv_last_variant), idempotent per-device "large-LDS
+ *     attribute set" flags, and the diagnostic counters behind am_diag_ring_clock (written by workgroup 0 of a ring launch);
  *   - all launches are asynchronous on `stream`; no call synchronises the device;
  *   - activations are NHWC ("pixel-major") with element type `dtype` (AM_F32 or AM_F16);
  *     accumulation is always fp32 (fp64 for BatchNorm statistics).
@@ -362,6 +365,14 @@ int am_adamw_step(float* p, const float* g, float* m, float* v, long long n, dou
                   double eps, double weight_decay, int step, float max_norm, const double* norm_sq, int* skipped,
                   am_stream_t stream);
 int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_stream_t stream);
+
+/* Gradient exchange -- SURVEY 8(b) sketched an `am_allreduce_bucket` (ncclAllReduce behind an event, on a side stream).  It is
+ * deliberately NOT an entry of this library: the RCCL communicator belongs to torch.distributed's process group (c10d
+ * ProcessGroupNCCL, the transport of the reference's DistributedDataParallel, train_bdd100k_ddp.py:497); c10d does not hand out
+ * its ncclComm_t, and a second communicator here would duplicate RCCL's bootstrap, buffers and streams.  What the wrapper would
+ * have contained -- record an event on the compute stream when a bucket of the flat gradient buffer is complete, wait for it
+ * and all-reduce the bucket on a side stream, join before am_adamw_step -- is training/ddp.py on dist.all_reduce(async_op=True);
+ * with the "nccl" backend the whole sequence is captured into the step's hipGraph (tests/test_hip_multigpu.py). */
 
 /* Packed conv operands from the fp32 master weight (hip/conv.py pack_fwd / pack_dgrad layouts; the reference keeps plain
  * OIHW nn.Conv2d weights, e.g. models/policy/trajectory_head.py:10-22): dst[i] = idx[i] < 0 ? 0 : (dtype)src[idx[i]].

@@ -161,3 +161,49 @@ def nuscenes_set_loss(model_out: Dict[str, torch.Tensor], gt_boxes: torch.Tensor
     loss_cls = F.cross_entropy(logits.view(-1, C), tgt_classes.view(-1), ignore_index=-1)
     loss_bbox = F.smooth_l1_loss(boxes, tgt_boxes, reduction="none").mean()
     return loss_cls + bbox_loss_weight * loss_bbox, loss_cls, loss_bbox, indices
+
+
+def detection_val_metrics(pred_boxes: torch.Tensor, targets_cxcywh: List[Dict[str, torch.Tensor]], indices) -> Dict[str, float]:
+    """training/train_bdd100k_ddp.py:267-291 as written there: per-image Python loops, `.item()` per image.
+    pred_boxes [B,Q,4]; targets_cxcywh: per image {'boxes' [Ni,4]}; indices: the matcher's per-image (pred_idx, tgt_idx)."""
+    from .matcher import box_cxcywh_to_xyxy
+
+    def box_iou(a, b):
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[None, :, :2])
+        rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+    iou_scores, recall_vals = [], []
+    for b, (p_idx, t_idx) in enumerate(indices):
+        if p_idx.numel() > 0:
+            pr = pred_boxes[b][p_idx]
+            gt = targets_cxcywh[b]["boxes"][t_idx]
+            iou_scores.append(box_iou(box_cxcywh_to_xyxy(pr), box_cxcywh_to_xyxy(gt)).diagonal().mean().item())
+        if t_idx.numel() > 0:
+            mat = box_iou(box_cxcywh_to_xyxy(pred_boxes[b]), box_cxcywh_to_xyxy(targets_cxcywh[b]["boxes"]))
+            recall_vals.append((mat.max(dim=0)[0] >= 0.5).float().mean().item())
+    return {"avg_iou": float(sum(iou_scores) / len(iou_scores)) if iou_scores else 0.0,
+            "recall_0.5": float(sum(recall_vals) / len(recall_vals)) if recall_vals else 0.0}
+
+
+def segmentation_val_metrics(outputs: torch.Tensor, masks: torch.Tensor) -> Dict[str, float]:
+    """training/train_bdd100k_ddp.py:299-325 as written there (loop over classes, `.item()` per class)."""
+    preds = outputs.argmax(dim=1)
+    ignore_mask = masks == 255
+    valid = ~ignore_mask
+    correct = (preds == masks) & valid
+    pixel_acc = correct.sum().float() / valid.sum().clamp(min=1).float()
+    ious = []
+    for cls in range(outputs.shape[1]):
+        gt_cls = masks == cls
+        if gt_cls.sum() == 0:
+            continue
+        pred_cls = preds == cls
+        inter = (pred_cls & gt_cls).sum().float()
+        union = ((pred_cls | gt_cls) & ~ignore_mask).sum().float()
+        ious.append((inter / union).item())
+    return {"pixel_acc": pixel_acc.item(), "mean_iou": sum(ious) / len(ious) if ious else 0.0}

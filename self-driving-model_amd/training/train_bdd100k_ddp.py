@@ -20,6 +20,7 @@ import torch.nn as nn
 from .. import runtime
 from ..hip import ops as hops
 from ..models.experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
+from . import metrics as val_metrics
 from . import synthetic
 from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
 from .hungarian_matcher import HungarianMatcher
@@ -193,17 +194,51 @@ class BDDTrainer:
         return float(total.item()) / max(1, len(self.train_loader))
 
     @torch.no_grad()
+    def _evaluate_detection_batch(self, batch):
+        """train_bdd100k_ddp.py:197-295: the validation loss (its box term is divided by the match count a SECOND time there,
+        :260-263 -- kept, it decides which checkpoint is "best") and avg IoU / recall@0.5; device tensors, no host sync."""
+        out = self.model(batch["image"].to(self.device))
+        gt_boxes, gt_labels = batch["bboxes"].to(self.device), batch["labels"].to(self.device)
+        _, cls_loss, bbox_loss, (rows, cols, count, _) = detection_set_loss(out, gt_boxes, gt_labels, self.core.num_classes, self.matcher,
+                                                                            self.config.get("bbox_loss_weight", 2.0))
+        n_matched = count.sum().clamp(min=1).to(bbox_loss.dtype)
+        loss = cls_loss + self.config.get("bbox_loss_weight", 2.0) * (bbox_loss / n_matched)
+        B, C, h, w = out["class_logits"].shape
+        pred_boxes = out["bbox_deltas"].permute(0, 2, 3, 1).reshape(B, h * w, 4)
+        n_tgt = (gt_labels != -1).sum(dim=1)
+        mets = val_metrics.detection_metrics(pred_boxes, box_xyxy_to_cxcywh(gt_boxes.float()), n_tgt, rows, cols, count)
+        return loss, mets
+
+    @torch.no_grad()
+    def _evaluate_segmentation_batch(self, batch):
+        """train_bdd100k_ddp.py:297-330: CE(ignore 255), pixel accuracy, mean IoU over the classes present."""
+        logits = self.model(batch["image"].to(self.device))
+        masks = batch["mask"].to(self.device)
+        return hops.CrossEntropy2d.apply(logits, masks, 255), val_metrics.segmentation_metrics(logits, masks, 255)
+
+    @torch.no_grad()
     def validate(self, epoch):
+        """Mean validation loss over the loader (the reference's return value, train_bdd100k_ddp.py:332-397); the epoch's metrics
+        (avg_iou / recall_0.5, or pixel_acc / mean_iou: means over batches, as the reference aggregates them) are left in
+        ``self.last_val_metrics``.  Accumulated on the device, read once."""
         self.model.eval()
         total = torch.zeros((), device=self.device)
+        agg = {}
         n = 0
         for batch in self.val_loader:
-            total += self._train_detection_batch(batch) if self.task == "detection" else self._train_segmentation_batch(batch)
+            loss, mets = self._evaluate_detection_batch(batch) if self.task == "detection" else self._evaluate_segmentation_batch(batch)
+            total += loss
+            for k, v in mets.items():
+                agg[k] = agg.get(k, 0) + v.float()
             n += 1
-        t = torch.stack([total, torch.tensor(float(n), device=self.device)])
+        keys = sorted(agg)
+        t = torch.stack([total, torch.tensor(float(n), device=self.device)] + [agg[k] for k in keys])
         if dist.is_initialized():
             dist.all_reduce(t)
-        return float(t[0].item()) / max(1.0, float(t[1].item()))
+        vals = t.tolist()
+        denom = max(1.0, vals[1])
+        self.last_val_metrics = {k: vals[2 + i] / denom for i, k in enumerate(keys)}
+        return vals[0] / denom
 
     def save_best(self, epoch, val_loss):
         if dist.is_initialized() and dist.get_rank() != 0:
@@ -219,7 +254,8 @@ class BDDTrainer:
             tr = self.train_epoch(epoch)
             va = self.validate(epoch)
             if (not dist.is_initialized()) or dist.get_rank() == 0:
-                print(f"Epoch {epoch + 1}/{self.config['epochs']}: train {tr:.4f} val {va:.4f} skipped {int(self.optimizer.skipped)}")
+                mets = " ".join(f"{k} {v:.4f}" for k, v in getattr(self, "last_val_metrics", {}).items())
+                print(f"Epoch {epoch + 1}/{self.config['epochs']}: train {tr:.4f} val {va:.4f} {mets} skipped {int(self.optimizer.skipped)}")
             if va < self.best_val_loss:
                 self.best_val_loss = va
                 self.save_best(epoch, va)

@@ -1449,3 +1449,50 @@ def test_grouped_moe_tail_matches_one_launch_per_layer():
     assert 0.42 < frac < 0.58, frac
     close(y[kept], 2.0 * y0[kept], rtol=1e-6, atol=1e-7, what="kept activations are rescaled by 1 / (1 - p)")
     assert not bool((kept & ~act).any())
+
+
+@pytest.mark.parametrize("task", ["drivable", "detection"])
+def test_expert_trainer_validation_loss_and_metrics(task):
+    """BDDTrainer.validate (train_bdd100k_ddp.py:197-397): mean validation loss plus the reference's metrics (pixel accuracy / mean
+    IoU, or matched-pair IoU / recall@0.5) from the device-side arithmetic of training/metrics.py -- against the oracle's restatement
+    of the reference loops fed with the same model outputs."""
+    from oracle import losses as ol
+    from oracle.matcher import HungarianMatcher as OM, box_xyxy_to_cxcywh
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.experts import BDDDetectionExpert, BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = _dev()
+    torch.manual_seed(13)
+    with runtime.precision(torch.float32):
+        if task == "drivable":
+            m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev)
+            b = synthetic.bdd_drivable_batch(2, 128, 160, 3, dev, seed=6)
+        else:
+            m = BDDDetectionExpert(10, pretrained_backbone=False).to(dev)
+            b = synthetic.bdd_detection_batch(2, 128, 160, 10, 6, dev, seed=6)
+        loader = synthetic.SyntheticLoader(b, 2)
+        tr = BDDTrainer(task, m, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t", "use_graph": False})
+        va = tr.validate(0)
+        mets = tr.last_val_metrics
+        m.eval()
+        with torch.no_grad():
+            out = m(b["image"])
+    assert np.isfinite(va) and all(0.0 <= v <= 1.0 for v in mets.values()), (va, mets)
+    if task == "drivable":
+        want = ol.segmentation_val_metrics(out.cpu(), b["mask"].cpu())
+        assert set(mets) == {"pixel_acc", "mean_iou"}
+        close(torch.tensor(va), ol.segmentation_loss(out.cpu(), b["mask"].cpu()), rtol=1e-4, atol=1e-6, what="val loss")
+    else:
+        B, C, h, w = out["class_logits"].shape
+        pl = out["class_logits"].permute(0, 2, 3, 1).reshape(B, h * w, C).cpu()
+        pb = out["bbox_deltas"].permute(0, 2, 3, 1).reshape(B, h * w, 4).cpu()
+        targets = []
+        for i in range(B):
+            keep = b["labels"][i].cpu() != -1
+            targets.append({"boxes": box_xyxy_to_cxcywh(b["bboxes"][i].cpu()[keep].float()), "labels": b["labels"][i].cpu()[keep]})
+        idx = OM(1.0, 5.0, 2.0)({"pred_logits": pl, "pred_boxes": pb}, targets)
+        want = ol.detection_val_metrics(pb, targets, idx)
+        assert set(mets) == {"avg_iou", "recall_0.5"}
+    for k, v in want.items():
+        assert abs(mets[k] - v) < 2e-4, (k, mets[k], v)

@@ -230,3 +230,43 @@ def test_grad_bucket_reducer_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ddp-ok") == 2
+
+
+def test_validation_metrics_match_the_reference_loops():
+    """training/metrics.py (batched device arithmetic, no host sync) against the oracle's restatement of the reference's per-image /
+    per-class loops (training/train_bdd100k_ddp.py:267-291, 299-325): detection avg IoU + recall@0.5 with ragged target counts,
+    an image without targets and degenerate boxes; segmentation pixel accuracy + mean IoU with ignored pixels and an absent class."""
+    import torch
+    from oracle import losses as ol
+    from oracle.matcher import HungarianMatcher as OM, box_cxcywh_to_xyxy
+    from self_driving_model_amd.training import metrics as M
+    g = torch.Generator().manual_seed(5)
+    B, Q, Nmax = 4, 40, 6
+    pred = torch.rand(B, Q, 4, generator=g) * torch.tensor([100.0, 60.0, 40.0, 30.0]) + torch.tensor([0.0, 0.0, 2.0, 2.0])
+    n_tgt = torch.tensor([6, 3, 0, 1])
+    tgt = torch.rand(B, Nmax, 4, generator=g) * torch.tensor([100.0, 60.0, 40.0, 30.0]) + torch.tensor([0.0, 0.0, 2.0, 2.0])
+    tgt[1, 0] = pred[1, 7]       # an exact hit: IoU 1
+    tgt[0, 1] = pred[0, 3] + torch.tensor([1.0, -1.0, 0.5, 0.0])
+    logits = torch.randn(B, Q, 5, generator=g)
+    labels = torch.randint(0, 5, (B, Nmax), generator=g)
+    targets = [{"boxes": tgt[b, : int(n_tgt[b])], "labels": labels[b, : int(n_tgt[b])]} for b in range(B)]
+    indices = OM(1.0, 5.0, 2.0)({"pred_logits": logits, "pred_boxes": pred}, targets)
+    k = max(1, int(n_tgt.max()))
+    rows = torch.full((B, k), -1, dtype=torch.int64); cols = torch.full((B, k), -1, dtype=torch.int64); count = torch.zeros(B, dtype=torch.int64)
+    for b, (pi, ti) in enumerate(indices):
+        rows[b, : pi.numel()], cols[b, : ti.numel()], count[b] = pi, ti, pi.numel()
+    got = M.detection_metrics(pred, tgt, n_tgt, rows, cols, count)
+    want = ol.detection_val_metrics(pred, targets, indices)
+    for key in want:
+        assert abs(float(got[key]) - want[key]) < 1e-6, (key, float(got[key]), want[key])
+    assert want["avg_iou"] > 0 and want["recall_0.5"] > 0
+    none = M.detection_metrics(pred, tgt, torch.zeros(B, dtype=torch.int64), rows, cols, torch.zeros(B, dtype=torch.int64))
+    assert float(none["avg_iou"]) == 0.0 and float(none["recall_0.5"]) == 0.0
+    # segmentation
+    out = torch.randn(2, 6, 17, 23, generator=g)
+    masks = torch.randint(0, 5, (2, 17, 23), generator=g)  # class 5 never present
+    masks[torch.rand(2, 17, 23, generator=g) < 0.1] = 255
+    got = M.segmentation_metrics(out, masks)
+    want = ol.segmentation_val_metrics(out, masks)
+    for key in want:
+        assert abs(float(got[key]) - want[key]) < 1e-6, (key, float(got[key]), want[key])
