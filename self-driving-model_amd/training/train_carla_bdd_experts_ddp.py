@@ -48,8 +48,20 @@ class Trainer(BDDTrainer):
         mask = sanitize_mask(batch["mask"].to(self.device), self.core.num_classes)
         return hops.CrossEntropy2d.apply(self.model(batch["image"].to(self.device)), mask.contiguous(), 255)
 
-    def validate(self, epoch=None):  # the reference's validate() takes no epoch
-        return super().validate(epoch)
+    @torch.no_grad()
+    def validate(self, epoch=None):
+        """train_carla_bdd_experts_ddp.py:171-184: the mean of the TRAINING objective over the validation loader (no metrics, no
+        epoch argument); accumulated on the device, read once."""
+        self.model.eval()
+        total = torch.zeros((), device=self.device)
+        n = 0
+        for batch in self.val_loader:
+            total += self._train_detection_batch(batch) if self.task == "detection" else self._train_segmentation_batch(batch)
+            n += 1
+        t = torch.stack([total, torch.tensor(float(n), device=self.device)])
+        if dist.is_initialized():
+            dist.all_reduce(t)
+        return float(t[0].item()) / max(1.0, float(t[1].item()))
 
     def save_best(self, epoch, val_loss):
         if dist.is_initialized() and dist.get_rank() != 0:

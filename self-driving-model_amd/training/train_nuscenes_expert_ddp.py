@@ -76,6 +76,11 @@ class NuScenesTrainer(BDDTrainer):
                                            self.config.get("bbox_loss_weight", 5.0))
         return total
 
+    @torch.no_grad()
+    def _evaluate_detection_batch(self, batch):
+        # validation objective = the training objective on the validation batches (the BDD box metrics assume 4-number boxes)
+        return self._train_detection_batch(batch), {}
+
     def save_best(self, epoch, val_loss):
         if dist.is_initialized() and dist.get_rank() != 0:
             return
