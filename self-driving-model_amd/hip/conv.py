@@ -372,15 +372,22 @@ def conv_wgrad_oihw(g: ConvGeom, x, dy, scale: float, w_param, s: "ConvSpec"):
     L.am_conv_wgrad_workspace_bytes(ctypes.byref(g), code, ctypes.byref(nbytes))
     if nbytes.value <= 0 or s.first:
         return NotImplemented
-    ws = torch.empty(nbytes.value // 4, dtype=torch.float32, device=x.device)
-    direct = _runtime().direct_grads() and _grad_ready(w_param) and tuple(w_param.shape) == (s.cout, s.cin, s.k, s.k)
-    out = w_param.grad if direct else torch.empty((s.cout, s.cin, s.k, s.k), dtype=torch.float32, device=x.device)
+    rt = _runtime()
+    direct = rt.direct_grads() and _grad_ready(w_param) and tuple(w_param.shape) == (s.cout, s.cin, s.k, s.k)
     flops = 2.0 * g.B * g.MH * g.MW * s.cin * s.k * s.k * g.N
-    _timed("conv_wgrad", flops, lambda: L.am_conv_wgrad_ws(ctypes.byref(g), code, ptr(x), ptr(dy), float(scale), ptr(ws), nbytes.value,
-                                                           ptr(out), s.cin, int(direct), stream()))
+
+    def launch(out):
+        ws = torch.empty(nbytes.value // 4, dtype=torch.float32, device=x.device)
+        _timed("conv_wgrad", flops, lambda: L.am_conv_wgrad_ws(ctypes.byref(g), code, ptr(x), ptr(dy), float(scale), ptr(ws), nbytes.value,
+                                                               ptr(out), s.cin, int(direct), stream()))
+        return ws
+
     if direct:
-        _runtime().grad_ready(w_param)
+        launch(w_param.grad)
+        rt.grad_ready(w_param)
         return None
+    out = torch.empty((s.cout, s.cin, s.k, s.k), dtype=torch.float32, device=x.device)
+    launch(out)
     return out
 
 

@@ -55,10 +55,9 @@ _DIRECT_GRADS = False
 
 
 def set_direct_grads(on: bool) -> None:
-    """When on, the backward kernels of Linear / LayerNorm / BatchNorm parameters accumulate straight into ``param.grad``
+    """When on, the backward kernels of conv / Linear / LayerNorm / BatchNorm parameters accumulate straight into ``param.grad``
     (the flat fp32 gradient buffer of FusedAdamW, zeroed once per step) and autograd sees no gradient for them: saves
-    a zero-fill and an add launch per parameter.  Must stay off when something listens to autograd's accumulate hooks
-    (the eager bucketed all-reduce)."""
+    a zero-fill and an add launch per parameter.  The kernels' call sites report finished gradients through grad_ready()."""
     global _DIRECT_GRADS
     _DIRECT_GRADS = bool(on)
 
