@@ -217,19 +217,20 @@ def main():
         fam = summ.get("conv_gemm", {"flops": 0.0, "ms": 1.0, "launches": 0})
         fam_ach = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the committed
-        # figure comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this command (scratch/pmc_bench.sh,
-        # FETCH_SIZE doubled per the gfx950 correction).  Algorithmic bytes (input + weights + output, each once) of the 31
-        # forward launches of the 4a step average 97.9 MB.
-        traffic, traffic_src = None, None
+        # figure comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this command (scratch/prof_r02.sh,
+        # FETCH_SIZE doubled per the gfx950 correction; the per-dispatch counter rows are kept in the JSON).  Algorithmic bytes
+        # (input + weights + output, each once) of the 25 forward launches of the 4a step average 105.6 MB.
+        traffic, traffic_src, alg_bytes = None, None, None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_pmc_dominant_kernel.json")))
-            if dom_name.startswith("conv_ring_k<256,256") and args.batch == 32:
-                traffic, traffic_src = int(pmc["hbm_bytes_per_launch"]), "profiles/r01c_pmc_dominant_kernel.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_dominant_kernel.json")))
+            if dom_name.startswith("conv_ring16_k<256,256") and args.batch == 32:
+                traffic, traffic_src = int(pmc["hbm_bytes_per_launch"]), "profiles/r02_pmc_dominant_kernel.json (raw per-dispatch counters inside)"
+                alg_bytes = float(pmc["algorithmic_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             pass
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": 97.9e6 if traffic else None,
+                           "algorithmic_bytes_per_launch": alg_bytes,
                            "kernel": dom_name, "in_kernel": in_kernel, "launches_per_step": dom["launches"] // 2,
                            "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                            "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),

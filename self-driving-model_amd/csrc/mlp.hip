@@ -520,22 +520,46 @@ __global__ __launch_bounds__(1024) void linear_group_bwd_input_k(const LinGroup 
   }
 }
 
-// dW[n][k] += sum_m dz[m][n] x[m][k], dbias[n] += sum_m dz[m][n]: thread per (n, k), grid (ceil(Kmax/256), Nmax, group)
+// dW[n][k] += sum_m dz[m][n] x[m][k], dbias[n] += sum_m dz[m][n].  A thread owns one k-column and a block of GW_NB output
+// channels: its x column (up to GW_MR rows per pass) sits in registers and is reused for every channel of the block, dz values
+// are wave-uniform loads -- the thread-per-(n, k) form re-read x once per channel through a dependent M-loop (35 us per launch
+// on the policy heads).  grid (ceil(Kmax/256), ceil(Nmax/GW_NB), group).
+constexpr int GW_NB = 8, GW_MR = 32;
 __global__ __launch_bounds__(256) void linear_group_bwd_weight_k(const LinGroup grp, int M) {
   const am_tail_linear& d = grp.p[blockIdx.z];
   if (d.dW == nullptr) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
-  const int n = blockIdx.y;
-  if (n >= d.N || k >= d.K) return;
-  float acc = 0.f, bacc = 0.f;
-  for (int m = 0; m < M; ++m) {
-    float g = d.dy[(size_t)m * d.lddy + n] * d.gscale;
-    if (d.yact && !(d.yact[(size_t)m * d.ldya + n] > 0.f)) g = 0.f;
-    acc += g * d.x[(size_t)m * d.ldx + k];
-    bacc += g;
+  const int nb = blockIdx.y * GW_NB;
+  if (nb >= d.N || (int)blockIdx.x * 256 >= d.K) return;
+  const bool kok = k < d.K;
+  float acc[GW_NB], bacc[GW_NB];
+#pragma unroll
+  for (int j = 0; j < GW_NB; ++j) { acc[j] = 0.f; bacc[j] = 0.f; }
+  for (int m0 = 0; m0 < M; m0 += GW_MR) {
+    float xv[GW_MR];
+#pragma unroll
+    for (int i = 0; i < GW_MR; ++i) xv[i] = (kok && m0 + i < M) ? d.x[(size_t)(m0 + i) * d.ldx + k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < GW_NB; ++j) {
+      const int n = nb + j;
+      if (n >= d.N) break;
+#pragma unroll
+      for (int i = 0; i < GW_MR; ++i) {
+        if (m0 + i >= M) break;
+        float g = d.dy[(size_t)(m0 + i) * d.lddy + n] * d.gscale;
+        if (d.yact && !(d.yact[(size_t)(m0 + i) * d.ldya + n] > 0.f)) g = 0.f;
+        acc[j] += g * xv[i];
+        bacc[j] += g;
+      }
+    }
   }
-  d.dW[(size_t)n * d.K + k] += acc;
-  if (d.dbias && k == 0) d.dbias[n] += bacc;
+#pragma unroll
+  for (int j = 0; j < GW_NB; ++j) {
+    const int n = nb + j;
+    if (n >= d.N) break;
+    if (kok) d.dW[(size_t)n * d.K + k] += acc[j];
+    if (d.dbias && k == 0) d.dbias[n] += bacc[j];
+  }
 }
 
 __global__ __launch_bounds__(256) void layernorm_group_fwd_k(const LnGroup grp, int M) {
@@ -751,7 +775,7 @@ extern "C" int am_moe_tail_linear_bwd(const am_tail_linear* group, int count, in
     AM_CHECK_LAUNCH();
   }
   if (kmax_w > 0) {
-    hipLaunchKernelGGL(linear_group_bwd_weight_k, dim3(am_cdiv(kmax_w, 256), nmax_w, count), dim3(256), 0, ST(stream), g, M);
+    hipLaunchKernelGGL(linear_group_bwd_weight_k, dim3(am_cdiv(kmax_w, 256), am_cdiv(nmax_w, GW_NB), count), dim3(256), 0, ST(stream), g, M);
     AM_CHECK_LAUNCH();
   }
   return AM_OK;
