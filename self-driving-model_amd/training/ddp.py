@@ -151,8 +151,11 @@ class GradBucketReducer:
     # ---- protocol shared by the trainers' hipGraph steps ---------------------------------------------------------
     def capture_begin(self) -> bool:
         """Call before capturing a step.  True: the capture records the bucket collectives (call finish() inside it, after
-        backward); False: hooks are silenced for the capture and every step ends with reduce_all()."""
-        in_graph = self.enabled and self.capturable
+        backward); False: hooks are silenced for the capture and every step ends with reduce_all().
+        A gradient buffer that is ONE bucket (the 11.5 MB of the frozen-expert gating stage) has nothing to overlap -- its only
+        collective starts when backward ends either way -- so it takes the plain post-replay all-reduce unless
+        AUTOMOE_GRAPH_ALLREDUCE=1 asks for the captured form; several buckets (trainable experts: 49-160 MB) are captured."""
+        in_graph = self.enabled and self.capturable and (len(self.buckets) > 1 or os.environ.get("AUTOMOE_GRAPH_ALLREDUCE") == "1")
         self.paused = self.enabled and not in_graph
         self.reset()
         return in_graph
