@@ -107,9 +107,18 @@ int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* 
 int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
                        const void* w, void* y, double* stats, am_stream_t stream);
 
+/* am_conv_gemm with a residual epilogue, y = act(conv(x, w) + bias[n] + res): the end of a ResNet BasicBlock in inference
+ * (torchvision resnet.py BasicBlock.forward `out += identity; out = relu(out)` as used by bdd_*_expert.py:9-11 through
+ * inference/run_automoe.py:34-53; eval-mode BatchNorm folded into w / bias by the caller), so no normalise + add pass and no
+ * raw conv output.  `res` has y's geometry (same pixel stride and channel offset).  The conv + bias is rounded to f16 before
+ * the residual is added (the same two roundings as am_conv_gemm followed by am_bn_apply).  f16 only; returns
+ * AM_ERR_UNSUPPORTED for shapes outside the LDS-DMA ring / weights-in-registers kernels (caller: am_conv_gemm + am_bn_apply). */
+int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x, const void* w, const float* bias, const void* res,
+                     int relu, void* y, am_stream_t stream);
+
 /* Diagnostic (bench.py roofline leg, kernel tests): which kernel the last am_conv_gemm / am_conv_first_fused / am_conv_wgrad call
  * made by the CALLING HOST THREAD launched (thread-local record).
- * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 (retired), 5 conv3x3_c64n64_k,
+ * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 (retired), 5 (retired),
  * 6 conv_gemm2_k, 7 (retired), 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
  * 11 conv_ring16_k<256,256>, 12 conv_ring16_k<256,128>, 13 wgrad_ring_k, 14 conv_wgrad_k (register-staged), 15 conv_s2d_wgrad_k. */
 int am_conv_last_variant(void);

@@ -8,6 +8,7 @@
 typedef _Float16 half_t;
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -27,6 +28,15 @@ __device__ __forceinline__ float am_to_f32(half_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T am_from_f32(float v);
 template <> __device__ __forceinline__ float am_from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ half_t am_from_f32<half_t>(float v) { return (half_t)v; }
+
+// Residual epilogue of the f16 conv kernels: two packed halves a (conv + bias, already rounded to f16) + b (residual), optional
+// ReLU.  A packed f16 add is correctly rounded, i.e. bit-identical with adding the two in fp32 and rounding once.
+__device__ __forceinline__ unsigned am_addh2_act(unsigned a, unsigned b, bool relu) {
+  half2_t v = __builtin_bit_cast(half2_t, a) + __builtin_bit_cast(half2_t, b);
+  const half2_t z = {(_Float16)0.f, (_Float16)0.f};
+  if (relu) v = __builtin_elementwise_max(v, z);
+  return __builtin_bit_cast(unsigned, v);
+}
 
 // 64-lane wave reductions (CDNA wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -609,10 +609,8 @@ int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const
                       hipStream_t s);  // conv_gemm2.hip
 int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
                     const float* shift, int relu, void* y, double* stats, hipStream_t s);  // conv_s2d.hip
-int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
+int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                               double* stats, hipStream_t s);  // conv_patch3.hip
-int am_conv3x3_c64n64_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
-                          hipStream_t s);  // conv_patch.hip
 
 thread_local int g_am_conv_variant = AM_CV_NONE;
 
@@ -637,8 +635,8 @@ extern "C" int am_set_tuning(int key, int value) {
 
 extern "C" int am_get_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : AM_ERR_ARG; }
 
-int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
-                     hipStream_t s);  // conv_ring.hip
+int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                     double* stats, hipStream_t s);  // conv_ring.hip
 
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;
@@ -666,15 +664,13 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     p.tap_off[t] = t < g->ntaps ? ((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->osplit > 0)  // split output rows (fused stride-2 dgrad): ring kernels only
-    return dtype == AM_F16 && bias == nullptr && !relu && stats == nullptr ? am_conv_ring_f16(g, x, w, bias, relu, y, stats, s) : AM_ERR_UNSUPPORTED;
+    return dtype == AM_F16 && bias == nullptr && !relu && stats == nullptr ? am_conv_ring_f16(g, x, w, bias, relu, nullptr, y, stats, s) : AM_ERR_UNSUPPORTED;
   if (dtype == AM_F16) {
     // 3-channel first layers on the space-to-depth image: weights-stationary patch kernel
     rc = am_conv_s2d_f16(g, 0, x, w, bias, nullptr, nullptr, relu, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
-    rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, y, stats, s);
-    if (rc != AM_ERR_UNSUPPORTED) return rc;
-    rc = am_conv3x3_c64n64_f16(g, x, w, bias, relu, y, stats, s);  // the same layers with a bias / ReLU epilogue or tensors >= 1 GiB
+    rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, nullptr, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads
     // into 64 channels) stays on the register-staged kernel
@@ -774,7 +770,21 @@ extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x,
 }
 
 int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
-                                  const float* bias, int relu, void* y, double* stats, hipStream_t s);  // conv_patch3.hip
+                                  const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s);  // conv_patch3.hip
+
+// y = act(conv + bias + res): the block end of an inference ResNet block (eval-mode BatchNorm folded into w / bias by the caller).
+extern "C" int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x, const void* w, const float* bias, const void* res,
+                                int relu, void* y, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !w || !y || !res || g->ntaps <= 0) return AM_ERR_ARG;
+  if (dtype != AM_F16 || g->osplit > 0) return AM_ERR_UNSUPPORTED;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, res, y, nullptr, s);
+  if (rc != AM_ERR_UNSUPPORTED) return rc;
+  return am_conv_ring_f16(g, x, w, bias, relu, res, y, nullptr, s);
+}
 
 extern "C" int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
                                   const void* w, void* y, double* stats, am_stream_t stream) {
@@ -782,7 +792,7 @@ extern "C" int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* 
   if (rc != AM_OK) return rc;
   if (!x || !w || !y || !pre_scale || !pre_shift) return AM_ERR_ARG;
   if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
-  return am_conv3x3_c64n64_duo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, y, stats, static_cast<hipStream_t>(stream));
+  return am_conv3x3_c64n64_duo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, nullptr, y, stats, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,

@@ -284,7 +284,7 @@ int launch2(const Conv2Params& p0, hipStream_t s) {
 
 // Called by am_conv_gemm (conv_gemm.hip) for f16 problems; returns AM_ERR_UNSUPPORTED when the shape is not covered
 // so the caller falls back to the register-staged kernel.
-int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
+int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y, double* stats,
                      hipStream_t s);  // conv_ring.hip
 
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
@@ -309,7 +309,7 @@ int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const
   {
     // Ring kernels (3-stage LDS-DMA pipeline).  The layers are LDS-bandwidth bound at one fragment read per MFMA (64x64 per
     // wave), so prefer 128x64 per wave (0.75 reads per MFMA) whenever the grid still fills the 256 CUs.
-    const int rc = am_conv_ring_f16(g, x, w, bias, relu, y, stats, s);
+    const int rc = am_conv_ring_f16(g, x, w, bias, relu, nullptr, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
   }
   if (run_bytes % 128 == 0) {

@@ -47,6 +47,10 @@ struct Patch3Params {
   // producing layer (bn.hip bn_apply_k arithmetic, fp32), so its normalised output never goes through HBM
   const float* pre_scale;
   const float* pre_shift;
+  // EPI variant (inference: BatchNorm folded into weights / bias): y = act(conv + bias[n] + res), res laid out like y
+  const float* bias;
+  const void* res;
+  int relu;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -58,6 +62,13 @@ __device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes
 
 typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
 
+// 16-byte load through a raw buffer descriptor (offsets >= bytes return zeros); the builtin, not asm: the compiler must know
+// when the registers are written
+__device__ __forceinline__ rsrc_words_t buffer_load16(const void* base, unsigned bytes, unsigned voff) {
+  return __builtin_bit_cast(rsrc_words_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                              __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), voff, 0, 0));
+}
+
 // 16-byte store through a raw buffer descriptor, as inline asm on purpose: hipcc's waitcnt pass puts s_waitcnt vmcnt(0)
 // in front of every store it can see while an LDS-DMA may be outstanding (it cannot prove the DMA source does not alias
 // the store), which would drain the patch prefetch and serialise the stores.  Offsets >= num_records are dropped by the
@@ -67,6 +78,12 @@ __device__ __forceinline__ void buffer_store16_asm(rsrc_words_t v, rsrc_words_t 
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 
+// EPI = false: raw output + BatchNorm statistics (training / train-mode BatchNorm).  EPI = true: no statistics (their 32
+// registers hold the bias and the residual tile instead); the residual is fetched in the store loop's layout (16-byte pieces,
+// full 64-byte half rows) at the START of the tile, lands under the MFMA phase, and is added to the f16-rounded conv + bias
+// with a packed f16 add (= the fp32 add of two f16 values rounded once), the same two roundings as conv -> f16 -> normalise pass.
+
+template <bool EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Params p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   rsrc_words_t yr;
@@ -165,10 +182,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     }
   };
 
-  // per-lane partial BN sums of the lane's 16 channels, folded across pixel lanes at the end
+  // per-lane partial BN sums of the lane's 16 channels, folded across pixel lanes at the end (EPI: the lane's 16 bias values)
   f32x16 ssum, ssq;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) {
+    ssum[r] = (EPI && p.bias != nullptr) ? p.bias[tn * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] : 0.f;
+    ssq[r] = 0.f;
+  }
+  const bool has_res = EPI && p.res != nullptr;
+  const bool relu_late = EPI && p.relu && has_res, relu_early = EPI && p.relu && !has_res;
 
   // fragment origin of this lane inside a patch: pixel fragment tm covers rows hsel*4 + tm*2 + frow, cols fcol
   const int fbase = ((hsel * 4 + frow) * PW + fcol) * PP + kg * 16;
@@ -202,6 +224,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const char* pt = gpatch + buf * PATCH_SLOT + fbase;
     f32x16 acc[2];  // [tm]
     half8_t fp[2][2];
+    rsrc_words_t resv[4];
+    if (EPI && has_res) {  // the store loop's pieces of the residual tile: in flight under the MFMA phase
+      const int img = tile / tiles_per_img;
+      const int rem = tile - img * tiles_per_img;
+      const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 64 + lane;
+        const int prow = q >> 2, cc = q & 3;
+        const int oy = ty * TH + hsel * 4 + (prow >> 5) * 2 + ((prow >> 4) & 1), ox = tx * TW + (prow & 15);
+        const unsigned vo = (oy < p.H && ox < p.W) ? (unsigned)((((img * p.H + oy) * p.W + ox) * p.ldo + p.y_coff + tn * 32 + cc * 8) * 2) : 0x80000000u;
+        resv[it] = buffer_load16(p.res, p.y_bytes, vo);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 36 + 1; ++s) {
       if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments (issued one MFMA pair ago)
@@ -246,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    if (ty * TH + TH > p.H || tx * TW + TW > p.W) {
+    if (!EPI && (ty * TH + TH > p.H || tx * TW + TW > p.W)) {
       // edge tile: pixels outside the image are not conv outputs -- zero them so they stay out of the statistics
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
@@ -255,10 +291,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
         for (int r = 0; r < 16; ++r) acc[tm][r] = ok ? acc[tm][r] : 0.f;
       }
     }
+    if (EPI) {  // ssum holds the bias
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      ssum += acc[tm];
-      ssq = __builtin_elementwise_fma(acc[tm], acc[tm], ssq);
+      for (int tm = 0; tm < 2; ++tm) {
+        acc[tm] += ssum;
+        if (relu_early) acc[tm] = __builtin_elementwise_max(acc[tm], ssq);  // (ssq stays zero)
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        ssum += acc[tm];
+        ssq = __builtin_elementwise_fma(acc[tm], acc[tm], ssq);
+      }
     }
     // stage 64 pixels x 32 channels in this wave's own area, then 64-byte half-rows go out with 16-byte stores
 #pragma unroll
@@ -278,12 +322,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
       const int prow = q >> 2, cc = q & 3;  // prow = tm*32 + pixel
       const int oy = ty * TH + hsel * 4 + (prow >> 5) * 2 + ((prow >> 4) & 1), ox = tx * TW + (prow & 15);
       const unsigned vo = (oy < p.H && ox < p.W) ? (unsigned)((((img * p.H + oy) * p.W + ox) * p.ldo + p.y_coff + tn * 32 + cc * 8) * 2) : 0x80000000u;
-      buffer_store16_asm(*reinterpret_cast<const rsrc_words_t*>(stg + prow * SP + cc * 16), yr, vo);
+      rsrc_words_t v = *reinterpret_cast<const rsrc_words_t*>(stg + prow * SP + cc * 16);
+      if (EPI && has_res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (int)am_addh2_act((unsigned)v[e], (unsigned)resv[it][e], relu_late);
+      }
+      buffer_store16_asm(v, yr, vo);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the next tile's writes
   }
 
-  if (p.stats != nullptr) {
+  if (!EPI && p.stats != nullptr) {
     // fold the 32 pixel lanes of each half-wave (xor < 32 stays inside the half), then the 4 waves that share a channel
     // block -> LDS -> one fp64 atomic per channel per workgroup
     float* part = reinterpret_cast<float*>(smem);  // [4 waves][32 channels][2] in the (now idle) patch area
@@ -322,18 +371,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
 }  // namespace amp3
 
 // Returns AM_ERR_UNSUPPORTED unless the geometry is exactly a dense 3x3 / stride 1 / pad 1, 64 -> 64 f16 convolution
-// (forward packing, tap order kh-major) without bias / ReLU epilogue, over a tensor small enough for 30-bit offsets.
+// (forward packing, tap order kh-major) over a tensor small enough for 30-bit offsets; with a bias / ReLU / residual epilogue
+// (the inference form) there are no statistics and no input transform.
 int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
-                                  const float* bias, int relu, void* y, double* stats, hipStream_t s);
+                                  const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s);
 
-int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y,
+// res (may be null): residual tensor with y's geometry, y = act(conv + bias + res)
+int am_conv3x3_c64n64_duo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                               double* stats, hipStream_t s) {
-  return am_conv3x3_c64n64_duo_pre_f16(g, x, nullptr, nullptr, w, bias, relu, y, stats, s);
+  return am_conv3x3_c64n64_duo_pre_f16(g, x, nullptr, nullptr, w, bias, relu, res, y, stats, s);
 }
 
 // pre_scale / pre_shift (both or neither): the convolution runs on relu(x * pre_scale[c] + pre_shift[c]).
 int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
-                                  const float* bias, int relu, void* y, double* stats, hipStream_t s) {
+                                  const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s) {
   using namespace amp3;
   if (g->ntaps != 9 || g->krun != 64 || g->N != 64 || g->pix_shift != 31) return AM_ERR_UNSUPPORTED;
   if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
@@ -343,7 +394,9 @@ int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const fl
   if (g->IW < TW || (long long)g->B * g->IH * g->IW < 64 * 1024) return AM_ERR_UNSUPPORTED;  // small problems: gather-GEMM
   const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
   const long long y_bytes = (long long)g->B * g->OH * g->OW * g->ldo * 2;
-  if (x_bytes >= (1ll << 30) || y_bytes >= (1ll << 31) || bias != nullptr || relu) return AM_ERR_UNSUPPORTED;  // BN trunk layers only
+  if (x_bytes >= (1ll << 30) || y_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
+  const bool epi = bias != nullptr || relu || res != nullptr;
+  if (epi && (stats != nullptr || pre_scale != nullptr)) return AM_ERR_UNSUPPORTED;  // a bias / ReLU / residual epilogue is the inference form: no statistics
   Patch3Params p;
   p.x = x; p.w = w; p.y = y; p.stats = stats;
   p.B = g->B; p.H = g->IH; p.W = g->IW; p.ldi = g->ldi; p.x_coff = g->x_coff; p.ldo = g->ldo; p.y_coff = g->y_coff;
@@ -354,16 +407,18 @@ int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const fl
   p.w_bytes = 64 * WROW;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.y_bytes = (unsigned)y_bytes;
-  static bool attr_done_dev[AM_MAX_DEVICES] = {};
-  bool& attr_done = attr_done_dev[am_current_device()];
+  p.bias = bias; p.res = res; p.relu = relu;
+  static bool attr_done_dev[AM_MAX_DEVICES][2] = {};
+  bool& attr_done = attr_done_dev[am_current_device()][epi ? 1 : 0];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64n64_duo_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return AM_ERR_LAUNCH;
+    const void* fn = epi ? reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<true>) : reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return AM_ERR_LAUNCH;
     attr_done = true;
   }
   const int grid = p.ntiles < 512 ? ((p.ntiles + 7) & ~7) : 512;  // two persistent workgroups per CU, a multiple of the 8 XCDs
   g_am_conv_variant = AM_CV_DUO_C64;
-  hipLaunchKernelGGL(conv3x3_c64n64_duo_k, dim3(grid), dim3(256), LDS_BYTES, s, p);
+  if (epi) hipLaunchKernelGGL(conv3x3_c64n64_duo_k<true>, dim3(grid), dim3(256), LDS_BYTES, s, p);
+  else hipLaunchKernelGGL(conv3x3_c64n64_duo_k<false>, dim3(grid), dim3(256), LDS_BYTES, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

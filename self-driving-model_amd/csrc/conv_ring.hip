@@ -25,6 +25,7 @@ struct RingParams {
   const void* w;
   void* y;
   const float* bias;
+  const void* res;  // optional residual with y's geometry: y = act(conv + bias + res) (see conv_ring16.hip)
   double* stats;
   int M, nk, kpt, Ktot, relu, mtiles, ntiles;
   unsigned x_bytes, w_bytes;
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
   {
     constexpr int SP = TN * 64 + 16;
     char* stg = smem + 8192 + wid * (TM * 32) * SP;  // past the stats scratch and the output-pixel table
-    if (p.bias == nullptr && !p.relu) {  // BN layers (almost every launch): convert and stage, nothing else
+    const T* __restrict__ res = static_cast<const T*>(p.res);
+    const bool relu_early = p.relu && res == nullptr;
+    if (p.bias == nullptr && !relu_early) {  // BN layers (almost every launch): convert and stage, nothing else
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
           for (int r = 0; r < 16; ++r) {
             const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             float v = acc[tm][tn][r] + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (relu_early) v = fmaxf(v, 0.f);
             *reinterpret_cast<half_t*>(stg + row * SP + (tn * 32 + (lane & 31)) * 2) = (half_t)v;
           }
       }
@@ -328,6 +331,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring_k(const RingParams p) 
     // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
     const int seg = (g.osplit > 0 && col0 >= g.osplit) ? g.osplit_stride - g.osplit : 0;
     const bool col_ok = col0 < ncols;
+    if (res != nullptr) {  // (never with split rows: the launcher checks)
+      uint4 rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) rv[it] = (offv[it] >= 0 && col_ok) ? *reinterpret_cast<const uint4*>(res + (unsigned)(offv[it] + col0)) : uint4{0, 0, 0, 0};
+      const bool act = p.relu != 0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        dat[it].x = am_addh2_act(dat[it].x, rv[it].x, act);
+        dat[it].y = am_addh2_act(dat[it].y, rv[it].y, act);
+        dat[it].z = am_addh2_act(dat[it].z, rv[it].z, act);
+        dat[it].w = am_addh2_act(dat[it].w, rv[it].w, act);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (offv[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(y + (unsigned)(offv[it] + col0 + seg)) = dat[it];
@@ -360,15 +376,17 @@ int launch_ring(const RingParams& p0, hipStream_t s) {
 
 // Called by am_conv_gemm2_f16 (conv_gemm2.hip); returns AM_ERR_UNSUPPORTED when the shape is not covered.
 // `npad_rows` = rows of the packed weight matrix (am_conv_npad).
-int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
-                       int variant, int* tile_out, hipStream_t s);  // conv_ring16.hip
+int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                       double* stats, int variant, int* tile_out, hipStream_t s);  // conv_ring16.hip
 
-int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
-                     hipStream_t s) {
+// res (may be null): residual tensor with y's geometry, y = act(conv + bias + res); not with split output rows.
+int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                     double* stats, hipStream_t s) {
   using namespace amr;
+  if (res != nullptr && g->osplit > 0) return AM_ERR_UNSUPPORTED;
   if (const int t = am_tuning(AM_TUNE_RING); t > 0) {  // 16x16x32 generation (conv_ring16.hip): the 256x256 tile
     int tile = 0;
-    const int rc = am_conv_ring16_f16(g, x, w, bias, relu, y, stats, t - 1, &tile, s);
+    const int rc = am_conv_ring16_f16(g, x, w, bias, relu, res, y, stats, t - 1, &tile, s);
     if (rc == AM_OK) g_am_conv_variant = tile == 1 ? AM_CV_RING16_256x256 : AM_CV_RING16_256x128;
     if (rc != AM_ERR_UNSUPPORTED) return rc;
   }
@@ -379,7 +397,7 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   if (x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
   RingParams p;
   p.g = *g;
-  p.x = x; p.w = w; p.y = y; p.bias = bias; p.stats = stats;
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res; p.stats = stats;
   p.M = g->B * g->MH * g->MW;
   p.Ktot = (int)Ktot;
   p.relu = relu;

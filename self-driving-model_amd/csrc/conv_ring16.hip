@@ -36,6 +36,8 @@ struct Params {
   const void* w;
   void* y;
   const float* bias;
+  const void* res;  // optional residual with y's geometry (inference: y = act(conv + bias + res)); added to the f16-rounded
+                    // conv + bias in the store loop (packed f16 add: the two roundings of conv -> f16 -> normalise pass)
   double* stats;
   int M, nk, kpt, Ktot, relu, mtiles, ntiles;
   unsigned x_bytes, w_bytes;
@@ -313,7 +315,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     constexpr int SP = WCOLS * 2 + 16;      // staging row pitch in bytes
     char* stg = smem + 4096 + wid * (TM * 16) * SP;
     float bv[TN][4];
-    const bool plain = p.bias == nullptr && !p.relu;  // BN layers (almost every launch): convert and stage, nothing else
+    const T* __restrict__ res = static_cast<const T*>(p.res);
+    const bool relu_early = p.relu && res == nullptr;
+    const bool plain = p.bias == nullptr && !relu_early;  // BN layers (almost every launch): convert and stage, nothing else
     if (!plain) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += bv[tn][r];
-            if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            if (relu_early) v[r] = fmaxf(v[r], 0.f);
           }
         }
         half4_t h;
@@ -362,6 +366,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     // split rows (fused stride-2 dgrad): the second half of the columns continues one image row further down
     const int seg = (g.osplit > 0 && col0 >= g.osplit) ? g.osplit_stride - g.osplit : 0;
     const bool col_ok = col0 < ncols;
+    if (res != nullptr) {  // (never with split rows: the launcher checks)
+      uint4 rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) rv[it] = (offv[it] >= 0 && col_ok) ? *reinterpret_cast<const uint4*>(res + (unsigned)(offv[it] + col0)) : uint4{0, 0, 0, 0};
+      const bool act = p.relu != 0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        dat[it].x = am_addh2_act(dat[it].x, rv[it].x, act);
+        dat[it].y = am_addh2_act(dat[it].y, rv[it].y, act);
+        dat[it].z = am_addh2_act(dat[it].z, rv[it].z, act);
+        dat[it].w = am_addh2_act(dat[it].w, rv[it].w, act);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (offv[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(y + (unsigned)(offv[it] + col0 + seg)) = dat[it];
@@ -396,9 +413,10 @@ int launch(const Params& p0, hipStream_t s) {
 
 // variant = SCHED of conv_ring16_k (0 block, 1 spread, 2 by wave age).
 // Returns AM_ERR_UNSUPPORTED when the shape is not covered; *tile_out: 1 = 256x256, 2 = 256x128.
-int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
-                       int variant, int* tile_out, hipStream_t s) {
+int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                       double* stats, int variant, int* tile_out, hipStream_t s) {
   using namespace amr16;
+  if (res != nullptr && g->osplit > 0) return AM_ERR_UNSUPPORTED;
   if (g->ntaps <= 0 || g->ntaps > MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0 || g->N <= 64) return AM_ERR_UNSUPPORTED;
   const long long x_bytes = (long long)g->B * g->IH * g->IW * g->ldi * 2;
   const long long Ktot = (long long)g->ntaps * g->krun;
@@ -406,7 +424,7 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
   if (x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
   Params p;
   p.g = *g;
-  p.x = x; p.w = w; p.y = y; p.bias = bias; p.stats = stats;
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res; p.stats = stats;
   p.M = g->B * g->MH * g->MW;
   p.Ktot = (int)Ktot;
   p.relu = relu;

@@ -449,10 +449,10 @@ class ConvBnAct(torch.autograd.Function):
             y, mean, rstd = raw, None, None
         else:
             use_batch = training or bn.running_mean is None
-            if not use_batch and residual is None and dtype == torch.float16 and FOLD_EVAL_BN and cfg.no_grad:
-                # Inference (eval-mode BatchNorm, nothing wants a gradient): y = act(conv(x, w) * scale + shift) with constant
-                # scale / shift is the same convolution with weights w * scale[n] and bias shift[n] -- no normalise pass, no
-                # raw tensor.  The folded master weight is rebuilt only when a parameter or running statistic changed.
+            if not use_batch and dtype == torch.float16 and FOLD_EVAL_BN and cfg.no_grad:
+                # Inference (eval-mode BatchNorm, nothing wants a gradient): y = act(conv(x, w) * scale + shift [+ residual]) with
+                # constant scale / shift is the same convolution with weights w * scale[n] and bias shift[n] -- no normalise
+                # pass, no raw tensor.  The folded master weight is rebuilt only when a parameter or running statistic changed.
                 # FusedAdamW, am_bn_finalize and graph replays write parameters / running statistics through raw pointers (no
                 # tensor version bump): the runtime's weight / statistics epochs stand in for them
                 key = (w._version, w.data_ptr(), gamma._version, beta._version, bn.running_mean._version, bn.running_var._version,
@@ -464,8 +464,21 @@ class ConvBnAct(torch.autograd.Function):
                         sh = sh + b.detach().float() * sc
                     cfg.cache.fold = (key, (w.detach().float() * sc.view(-1, 1, 1, 1)).contiguous(), sh.contiguous(), PackedWeights())
                 _, wf, bf, cache_f = cfg.cache.fold
-                conv_gemm(g, x, cache_f.get_fwd(wf, s, dtype), bf, cfg.relu, raw, None, k_real=s.cin * s.k * s.k)
-                return raw
+                if residual is None:
+                    conv_gemm(g, x, cache_f.get_fwd(wf, s, dtype), bf, cfg.relu, raw, None, k_real=s.cin * s.k * s.k)
+                    return raw
+                # block end: act(conv + bias + identity) in the conv epilogue (am_conv_gemm_res) -- no normalise + add pass.
+                # Shapes without that epilogue fall through to the unfolded sequence below
+                if tuple(residual.shape) == tuple(raw.shape) and residual.is_contiguous() and residual.dtype == dtype:
+                    import ctypes
+                    flops = 2.0 * g.B * g.MH * g.MW * s.cin * s.k * s.k * g.N
+                    try:
+                        _timed("conv_gemm", flops, lambda: L.am_conv_gemm_res(ctypes.byref(g), dt_code(dtype), ptr(x), ptr(cache_f.get_fwd(wf, s, dtype)),
+                                                                              ptr(bf), ptr(residual), int(cfg.relu), ptr(raw), stream()))
+                        return raw
+                    except RuntimeError as e:
+                        if "UNSUPPORTED" not in str(e):
+                            raise
             stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev) if use_batch else None
             # Frozen first layer in train-mode BN (AutoMoE's gating stage): two light passes over the image instead of
             # conv -> raw output -> normalise pass.  Only when nothing here needs a gradient (raw output is not kept).

@@ -849,19 +849,41 @@ def test_shortcut_conv_takes_the_two_workgroup_tile(case):
     assert rel_err(nchw(outs[8], cout), F.conv2d(x4, w, stride=2)) < 2e-3
 
 
-def test_conv3x3_c64n64_fallback_kernel_with_bias_relu_epilogue():
-    """64 -> 64 3x3 layers WITH a bias / ReLU epilogue (not a BatchNorm trunk layer) are outside the weights-in-registers duo kernel;
-    the LDS-weights patch kernel conv3x3_c64n64_k (conv_patch.hip) takes them: pinned by name, checked against torch."""
+@pytest.mark.parametrize("cin,cout,B,H,W,kernel", [(64, 64, 2, 180, 320, "conv3x3_c64n64_duo_k"), (128, 128, 4, 90, 160, "conv_ring_k<256,128>"),
+                                                   (256, 256, 2, 160, 160, "conv_ring16_k<256,256>")])
+def test_conv_bias_relu_residual_epilogue(cin, cout, B, H, W, kernel):
+    """Inference form of a ResNet block end (eval-mode BatchNorm folded into weights / bias): y = relu(conv(x, w) + b + identity)
+    in the conv epilogue (am_conv_gemm_res), and the bias + ReLU epilogue of am_conv_gemm on the same kernels.  Checked against
+    torch, and bit for bit against the two-pass sequence (conv + bias rounded to f16, then add + ReLU rounded to f16)."""
+    import ctypes
     from self_driving_model_amd.hip import conv as hc
-    B, H, W = 2, 180, 320
-    g = torch.Generator().manual_seed(77)
-    x = torch.randn(B, 64, H, W, generator=g).half().float()
-    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
-    b = torch.randn(64, generator=g)
-    yr = F.relu(F.conv2d(x, w, b, padding=1))
-    s = hc.ConvSpec(64, 64, 3, 1, 1)
-    y = torch.zeros(B, H, W, 64, dtype=torch.float16, device=_dev())
-    hc.conv_gemm(hc.fwd_geom(s, B, H, W, 64, 64, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), b.to(_dev()), True, y, None)
-    launched_kernel("conv3x3_c64n64_k", what="c64n64 with bias + relu")
-    torch.cuda.synchronize()
-    close(nchw(y, 64), yr, rtol=3e-3, atol=3e-3)
+    from self_driving_model_amd.hip import lib
+    L = lib.get()
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).half().float()
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g).half().float()
+    s = hc.ConvSpec(cin, cout, 3, 1, 1)
+    geom = hc.fwd_geom(s, B, H, W, cin, cout, 2)
+    xd, wp, bd, rd = nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), b.to(_dev()), nhwc(r, torch.float16)
+    conv = F.conv2d(x, w, b, padding=1)
+    # bias + ReLU, no residual
+    y0 = torch.zeros(B, H, W, cout, dtype=torch.float16, device=_dev())
+    hc.conv_gemm(geom, xd, wp, bd, True, y0, None)
+    launched_kernel(kernel, what=f"{cin}->{cout} bias + relu")
+    close(nchw(y0, cout), F.relu(conv), rtol=3e-3, atol=3e-3)
+    # bias only (the first pass of the two-pass sequence)
+    y1 = torch.zeros_like(y0)
+    hc.conv_gemm(geom, xd, wp, bd, False, y1, None)
+    for relu in (True, False):
+        y2 = torch.zeros_like(y0)
+        L.am_conv_gemm_res(ctypes.byref(geom), hc.dt_code(torch.float16), hc.ptr(xd), hc.ptr(wp), hc.ptr(bd), hc.ptr(rd), int(relu), hc.ptr(y2),
+                           hc.stream())
+        launched_kernel(kernel, what=f"{cin}->{cout} residual epilogue")
+        torch.cuda.synchronize()
+        ref = conv + r
+        close(nchw(y2, cout), F.relu(ref) if relu else ref, rtol=3e-3, atol=4e-3)
+        two_pass = y1.float() + rd.float()
+        two_pass = (F.relu(two_pass) if relu else two_pass).half()
+        assert torch.equal(y2, two_pass), f"residual epilogue differs from the two-pass sequence (relu={relu})"
