@@ -132,13 +132,16 @@ int am_conv_last_variant(void);
  *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k.
  *   AM_TUNE_WGRAD_MAX_SLABS   am_conv_wgrad_ws keeps one slab per pixel chunk up to this many chunks; beyond it the chunks add
  *                  atomically into ONE zero-filled slab (0: always; a huge value: never).
- *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256. */
+ *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256;
+ *   AM_TUNE_DEV            kernel-development switches (scratch/ab_*.py timing experiments: parts of a kernel compiled in but
+ *                          skipped); 0 in production, results are wrong otherwise. */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
 #define AM_TUNE_WGRAD_MAX_SLABS 3
 #define AM_TUNE_RING_SHORT_K 4
-#define AM_TUNE_COUNT 5
+#define AM_TUNE_DEV 5
+#define AM_TUNE_COUNT 6
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 
@@ -268,6 +271,17 @@ int am_ce2d_fwd(const float* logits, const long long* target, int B, int C, long
                 double* acc2, am_stream_t stream);
 int am_ce2d_bwd(const float* logits, const long long* target, int B, int C, long long HW, long long ignore_index,
                 const double* acc2, const float* grad_out, float* dlogits, am_stream_t stream);
+
+/* Dense-expert training loss fused (bdd_segmentation_expert.py:22 F.interpolate + train_bdd100k_ddp.py:89-100 CrossEntropyLoss(
+ * ignore_index=255)): loss sum / valid count (acc2, as am_ce2d_fwd) and the UNNORMALISED gradient with respect to the
+ * low-resolution NHWC logits, G[B,h,w,C] fp32 = sum over output pixels of (softmax - onehot) * interpolation weight, in one pass
+ * over the labels; the [B,C,H,W] logits are never written.  Deterministic (every G cell has one owner, fixed summation order).
+ * C = 3 or 19 (AM_ERR_UNSUPPORTED otherwise: caller uses am_bilinear_up_* + am_ce2d_*).
+ * bwd: dlow[b,y,x,c] = G * grad_out[0] / max(count, 1) * mul in `dtype` at pixel stride ld. */
+int am_upsample_ce2d_fwd(int dtype, const void* low, int ld, const long long* target, int B, int C, int h, int w, int H, int W,
+                         long long ignore_index, double* acc2, float* G, am_stream_t stream);
+int am_upsample_ce2d_bwd(int dtype, const float* G, const double* acc2, const float* grad_out, float mul, void* dlow, int ld,
+                         int B, int C, int h, int w, am_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * MoE tail (fp32): nn.Linear / ReLU / Dropout / LayerNorm of expert_extractors.py:30-34,

@@ -29,6 +29,7 @@ struct S2dWgradParams {
   const void* yout;  // BN+ReLU output (ReLU mask), NULL without ReLU
   const float* mean; const float* rstd; const float* coef;  // coef = [3][N] from am_bn_bwd_finalize
   int relu;
+  int dbg;
 };
 
 typedef __attribute__((address_space(3))) s4v* lds_s4v;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
       if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff) {
         const long long off = ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8;
         v = *reinterpret_cast<const uint4*>(dy + off);
-        if constexpr (BNF) {
+        if (BNF && !(p.dbg & 2)) {
           const uint4 xr = *reinterpret_cast<const uint4*>(raw + off);
           uint4 yr = make_uint4(0u, 0u, 0u, 0u);
           if (p.relu) yr = *reinterpret_cast<const uint4*>(yout + off);
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
     }
   }
 
+  if (p.dbg & 1) return;
   // ---- flush: waves that share a channel block add up in LDS, then one fp32 atomic per element per workgroup ----
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);  // [NT][32][KTOT]
@@ -239,6 +241,7 @@ int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, 
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
   p.raw = raw; p.yout = yout; p.mean = mean; p.rstd = rstd; p.coef = coef; p.relu = relu;
+  p.dbg = am_tuning(AM_TUNE_DEV);
   if (raw != nullptr) {
     if (!mean || !rstd || !coef || (relu && !yout)) return AM_ERR_ARG;
     if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, true>(p, s) : launch<4, 1, true>(p, s);

@@ -540,6 +540,151 @@ __global__ __launch_bounds__(256) void ce2d_bwd_k(const float* __restrict__ logi
   }
 }
 
+// ---- bilinear upsample + pixel-wise cross entropy without the full-resolution logits -------------------------------------------
+// loss = CrossEntropy(F.interpolate(low, (H, W), bilinear), target, ignore_index) and d loss / d low in ONE pass over the
+// labels: the [B, C, H, W] fp32 logits (70 MB per image for the segmentation expert) and their gradient are never written.
+// One workgroup per (image b, low-resolution row y, group of CB low-resolution columns): it OWNS the gradient cells
+// G[b, y, ka..kb) (plain stores, no atomics, no zero-fill, deterministic) and visits every output pixel whose 2x2 source
+// neighbourhood touches them -- a pixel is visited by up to two rows (its y0 and y1) and, at group borders, two groups; its
+// softmax is recomputed per visit (a few hundred VALU instructions against 8 B of label and no logits traffic).  The pixel's
+// loss is counted by the workgroup that owns its (y0, x0) cell.  Interpolation arithmetic = bilinear_fwd_k's, softmax =
+// ce2d_*_k's with v_exp_f32; G is the UNNORMALISED gradient (sum over pixels of (softmax - onehot) * weight): the backward
+// entry scales it by grad_out / count.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void upsample_ce2d_k(const T* __restrict__ low, int ld, const long long* __restrict__ target, int h,
+                                                       int w, int H, int W, float sh, float sw, long long ignore_index,
+                                                       double* __restrict__ acc, float* __restrict__ G, int xgroups, int CB) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x;
+  const int xg = blockIdx.x % xgroups;
+  const int y = (blockIdx.x / xgroups) % h;
+  const int b = blockIdx.x / (xgroups * h);
+  const int ka = xg * CB, kb = min(ka + CB, w);
+  const int ncell = CB + 2;                      // cells ka-1 .. kb (clamped to the map)
+  float* rows = sm;                              // [3][ncell][C]: low rows y-1, y, y+1
+  float* part = rows + 3 * ncell * C;            // [256][2C]
+  int* px = reinterpret_cast<int*>(part + 256 * 2 * C);  // [256][2]: the owned cells thread tid adds to (-1: none)
+  double* red = reinterpret_cast<double*>(px + 512);     // [2][4]
+  for (int i = tid; i < 3 * ncell * C; i += 256) {
+    const int c = i % C, k = (i / C) % ncell, r = i / (C * ncell);
+    const int yy = min(max(y - 1 + r, 0), h - 1), xx = min(max(ka - 1 + k, 0), w - 1);
+    rows[i] = am_to_f32(low[(((long long)b * h + yy) * w + xx) * ld + c]);
+  }
+  // candidate output rows / columns: conservative ranges, exact tests inside (as bilinear_bwd_k)
+  int Ylo = (int)floorf(((float)y - 1.f + 0.5f) / sh - 0.5f) - 1, Yhi = (int)ceilf(((float)y + 1.f + 0.5f) / sh - 0.5f) + 1;
+  Ylo = max(Ylo, 0); Yhi = min(Yhi, H - 1);
+  if (y == 0) Ylo = 0;
+  if (y == h - 1) Yhi = H - 1;
+  int Xlo = (int)floorf(((float)ka - 1.f + 0.5f) / sw - 0.5f) - 1, Xhi = (int)ceilf(((float)kb + 0.5f) / sw - 0.5f) + 1;
+  Xlo = max(Xlo, 0); Xhi = min(Xhi, W - 1);
+  if (ka == 0) Xlo = 0;
+  if (kb == w) Xhi = W - 1;
+  __syncthreads();
+
+  double ls = 0.0, cnt = 0.0;
+  float bin = 0.f;  // thread j < (kb-ka)*C owns G[b, y, ka + j / C, j % C]
+  for (int Xb = Xlo; Xb <= Xhi; Xb += 256) {
+    const int X = Xb + tid;
+    int x0 = 0, x1 = 0;
+    float lx = 0.f;
+    if (X <= Xhi) src_index(X, sw, w, x0, x1, lx);
+    const bool own0 = X <= Xhi && x0 >= ka && x0 < kb, own1 = X <= Xhi && x1 >= ka && x1 < kb;
+    float a0[C], a1[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) a0[c] = a1[c] = 0.f;
+    if (own0 || own1) {
+      const float hx = 1.f - lx;
+      const float* r0 = rows + (x0 - (ka - 1)) * C;  // own1 => x0 >= ka - 1; own0 => x1 <= kb
+      const float* r1 = rows + (x1 - (ka - 1)) * C;
+      float rm[C], rc[C], rp[C];  // the three low rows interpolated along x at this column
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        rm[c] = hx * r0[c] + lx * r1[c];
+        rc[c] = hx * r0[ncell * C + c] + lx * r1[ncell * C + c];
+        rp[c] = hx * r0[2 * ncell * C + c] + lx * r1[2 * ncell * C + c];
+      }
+      const long long* tcol = target + (long long)b * H * W + X;
+      for (int Y = Ylo; Y <= Yhi; ++Y) {
+        int y0, y1;
+        float ly;
+        src_index(Y, sh, h, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == y) wy += 1.f - ly;
+        if (y1 == y) wy += ly;
+        if (wy == 0.f) continue;
+        const long long t = tcol[(long long)Y * W];
+        if (t == ignore_index) continue;
+        const float hy = 1.f - ly;
+        const bool top_c = y0 == y, bot_c = y1 == y;
+        float v[C];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          v[c] = hy * (top_c ? rc[c] : rm[c]) + ly * (bot_c ? rc[c] : rp[c]);
+          mx = fmaxf(mx, v[c]);
+        }
+        float se = 0.f, vt = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          vt = (c == (int)t) ? v[c] : vt;
+          v[c] = __expf(v[c] - mx);
+          se += v[c];
+        }
+        if (top_c && own0) {  // this workgroup owns the pixel's (y0, x0) cell: its loss is counted here, once
+          ls += (double)(__logf(se) + mx - ((t >= 0 && t < C) ? vt : 0.f));
+          cnt += 1.0;
+        }
+        const float inv = 1.f / se;
+        const float w0 = wy * (1.f - lx), w1 = wy * lx;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float gpx = v[c] * inv - ((c == (int)t) ? 1.f : 0.f);
+          a0[c] += gpx * w0;
+          a1[c] += gpx * w1;
+        }
+      }
+    }
+    px[2 * tid] = own0 ? x0 : -1;
+    px[2 * tid + 1] = own1 ? x1 : -1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      part[tid * 2 * C + c] = a0[c];
+      part[tid * 2 * C + C + c] = a1[c];
+    }
+    __syncthreads();
+    if (tid < (kb - ka) * C) {  // fixed summation order: deterministic
+      const int k = ka + tid / C, c = tid % C;
+      for (int i = 0; i < 256; ++i) {
+        if (px[2 * i] == k) bin += part[i * 2 * C + c];
+        if (px[2 * i + 1] == k) bin += part[i * 2 * C + C + c];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < (kb - ka) * C) G[(((long long)b * h + y) * w + ka + tid / C) * C + tid % C] = bin;
+  ls = wave_sum(ls);
+  cnt = wave_sum(cnt);
+  if ((tid & 63) == 0) { red[tid >> 6] = ls; red[4 + (tid >> 6)] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    const double l = red[0] + red[1] + red[2] + red[3], n = red[4] + red[5] + red[6] + red[7];
+    if (n != 0.0) {
+      atomicAdd(acc + 0, l);
+      atomicAdd(acc + 1, n);
+    }
+  }
+}
+
+// dlow[b, y, x, c] = G * grad_out / count * mul (pad channels of the pixel stride stay as the caller initialised them)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_ce2d_bwd_k(const float* __restrict__ G, const double* __restrict__ acc,
+                                                           const float* __restrict__ gout, float mul, T* __restrict__ dlow, int ld, int C,
+                                                           long long total) {
+  const float g = gout[0] / (float)fmax(acc[1], 1.0) * mul;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    dlow[(i / C) * ld + i % C] = am_from_f32<T>(G[i] * g);
+}
+
 }  // namespace
 
 #define DT_OK(d) ((d) == AM_F16 || (d) == AM_F32)
@@ -696,6 +841,47 @@ extern "C" int am_ce2d_bwd(const float* logits, const long long* target, int B, 
   const long long total = HW * B;
   if (total == 0) return AM_OK;
   hipLaunchKernelGGL(ce2d_bwd_k, dim3(ew_grid(total)), dim3(256), 0, ST(stream), logits, target, C, HW, total, ignore_index, acc2, grad_out, dlogits);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+template <typename T, int C>
+static int launch_upsample_ce2d(const void* low, int ld, const long long* target, int B, int h, int w, int H, int W, long long ignore_index,
+                                double* acc2, float* G, hipStream_t s) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  // columns per workgroup: the widest group whose output footprint ((CB + 1) / sw + 2 columns) fits one 256-thread sweep
+  int CB = (int)floorf(254.f * sw) - 1;
+  CB = CB < 1 ? 1 : (CB > w ? w : CB);
+  if (CB * C > 256) CB = 256 / C;
+  const int xgroups = (w + CB - 1) / CB;
+  const size_t lds = sizeof(float) * ((size_t)3 * (CB + 2) * C + 256 * 2 * C) + sizeof(int) * 512 + sizeof(double) * 8;
+  hipLaunchKernelGGL((upsample_ce2d_k<T, C>), dim3((unsigned)(B * h * xgroups)), dim3(256), lds, s, (const T*)low, ld, target, h, w, H, W, sh, sw,
+                     ignore_index, acc2, G, xgroups, CB);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_upsample_ce2d_fwd(int dtype, const void* low, int ld, const long long* target, int B, int C, int h, int w, int H, int W,
+                                    long long ignore_index, double* acc2, float* G, am_stream_t stream) {
+  if (!DT_OK(dtype) || !low || !target || !acc2 || !G || C <= 0 || C > ld || h <= 0 || w <= 0 || H <= 0 || W <= 0) return AM_ERR_ARG;
+  if (C != 3 && C != 19) return AM_ERR_UNSUPPORTED;  // the class counts of the reference's dense experts (register-resident per-class state)
+  if ((long long)B * h * w >= (1ll << 31) / 64) return AM_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), ST(stream)) != hipSuccess) return AM_ERR_LAUNCH;
+  if (B == 0) return AM_OK;
+  hipStream_t s = ST(stream);
+  if (dtype == AM_F16) return C == 3 ? launch_upsample_ce2d<half_t, 3>(low, ld, target, B, h, w, H, W, ignore_index, acc2, G, s)
+                                     : launch_upsample_ce2d<half_t, 19>(low, ld, target, B, h, w, H, W, ignore_index, acc2, G, s);
+  return C == 3 ? launch_upsample_ce2d<float, 3>(low, ld, target, B, h, w, H, W, ignore_index, acc2, G, s)
+                : launch_upsample_ce2d<float, 19>(low, ld, target, B, h, w, H, W, ignore_index, acc2, G, s);
+}
+
+extern "C" int am_upsample_ce2d_bwd(int dtype, const float* G, const double* acc2, const float* grad_out, float mul, void* dlow, int ld,
+                                    int B, int C, int h, int w, am_stream_t stream) {
+  if (!DT_OK(dtype) || !G || !acc2 || !grad_out || !dlow || C <= 0 || C > ld) return AM_ERR_ARG;
+  const long long total = (long long)B * h * w * C;
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(upsample_ce2d_bwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), G, acc2, grad_out, mul, (half_t*)dlow, ld, C, total);
+  else hipLaunchKernelGGL(upsample_ce2d_bwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), G, acc2, grad_out, mul, (float*)dlow, ld, C, total);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -240,6 +240,41 @@ class CrossEntropy2d(torch.autograd.Function):
         return d, None, None
 
 
+class UpsampleCrossEntropy(torch.autograd.Function):
+    """CrossEntropy2d(BilinearUp(low), target) without the [B,C,H,W] logits (am_upsample_ce2d_*): the dense experts' training
+    loss straight from the low-resolution NHWC logits.  ``supported(C)`` tells whether the class count has a kernel."""
+
+    @staticmethod
+    def supported(C: int) -> bool:
+        return C in (3, 19)
+
+    @staticmethod
+    def forward(ctx, low, target, C: int, H: int, W: int, ignore_index: int, loss_scale: float):
+        require_hip(low, "low-resolution logits")
+        low = low.contiguous()
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            target = target.long()
+        B, h, w, ld = low.shape
+        if tuple(target.shape) != (B, H, W):
+            raise ValueError(f"target shape {tuple(target.shape)} does not match logits upsampled to {(B, H, W)}")
+        acc = torch.empty(2, dtype=torch.float64, device=low.device)
+        G = torch.empty((B, h, w, C), dtype=torch.float32, device=low.device)
+        _L().am_upsample_ce2d_fwd(dt_code(low.dtype), ptr(low), ld, ptr(target), B, C, h, w, H, W, int(ignore_index), ptr(acc), ptr(G), stream())
+        ctx.save_for_backward(G, acc)
+        ctx.meta = (low.dtype, B, C, h, w, ld, loss_scale)
+        return (acc[0] / acc[1]).float()  # 0/0 -> nan when every pixel is ignored, as torch
+
+    @staticmethod
+    def backward(ctx, g):
+        G, acc = ctx.saved_tensors
+        dtype, B, C, h, w, ld, ls = ctx.meta
+        g = g.contiguous().float()
+        dlow = (torch.zeros if ld != C else torch.empty)((B, h, w, ld), dtype=dtype, device=g.device)
+        _L().am_upsample_ce2d_bwd(dt_code(dtype), ptr(G), ptr(acc), ptr(g), float(ls), ptr(dlow), ld, B, C, h, w, stream())
+        return dlow, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # fp32 MoE tail
 # --------------------------------------------------------------------------------------------

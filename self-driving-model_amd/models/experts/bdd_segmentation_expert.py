@@ -30,6 +30,17 @@ class _DenseExpert(nn.Module):
         low = self.lowres_nhwc(xin)
         return hops.UpsampleGap.apply(low, self.num_classes, x.shape[-2], x.shape[-1], runtime.loss_scale()), low
 
+    def pixel_ce_loss(self, x, target, ignore_index=255):
+        """nn.CrossEntropyLoss(ignore_index)(self(x), target) (train_bdd100k_ddp.py:89-100) without writing the full-resolution
+        logits: upsample + cross entropy + their backward run on the low-resolution logits (hops.UpsampleCrossEntropy).
+        Class counts without that kernel take forward() + CrossEntropy2d."""
+        if not hops.UpsampleCrossEntropy.supported(self.num_classes):
+            return hops.CrossEntropy2d.apply(self(x), target, ignore_index)
+        runtime.begin_step(x.device)
+        low = self.lowres_nhwc(hops.image_to_nhwc(x, runtime.compute_dtype()))
+        hconv.flush_bn_counters()
+        return hops.UpsampleCrossEntropy.apply(low, target, self.num_classes, x.shape[-2], x.shape[-1], ignore_index, runtime.loss_scale())
+
     def forward(self, x, nhwc_input=None):
         if nhwc_input is None:
             runtime.begin_step(x.device)

@@ -27,6 +27,9 @@ from .hungarian_matcher import HungarianMatcher
 from .optim import FusedAdamW
 
 
+FUSE_SEG_LOSS = True  # tests flip this to compare the fused dense-expert loss with upsample -> CrossEntropy2d
+
+
 def box_xyxy_to_cxcywh(b: torch.Tensor) -> torch.Tensor:
     x1, y1, x2, y2 = b.unbind(-1)
     return torch.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], dim=-1)
@@ -111,8 +114,15 @@ class BDDTrainer:
                                             self.core.num_classes, self.matcher, self.config.get("bbox_loss_weight", 2.0))
         return total
 
+    def _segmentation_loss(self, images, masks):
+        """criterion(model(images), masks) of train_bdd100k_ddp.py:89-100.  The dense experts form it from their low-resolution logits
+        (pixel_ce_loss: upsample + cross entropy fused, no [B,C,H,W] tensor); FUSE_SEG_LOSS = False keeps the two-op sequence."""
+        if FUSE_SEG_LOSS and hasattr(self.core, "pixel_ce_loss"):
+            return self.core.pixel_ce_loss(images, masks, 255)
+        return hops.CrossEntropy2d.apply(self.model(images), masks, 255)
+
     def _train_segmentation_batch(self, batch):
-        return hops.CrossEntropy2d.apply(self.model(batch["image"].to(self.device)), batch["mask"].to(self.device), 255)
+        return self._segmentation_loss(batch["image"].to(self.device), batch["mask"].to(self.device))
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()

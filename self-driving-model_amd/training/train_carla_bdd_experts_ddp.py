@@ -46,7 +46,7 @@ class Trainer(BDDTrainer):
 
     def _train_segmentation_batch(self, batch):
         mask = sanitize_mask(batch["mask"].to(self.device), self.core.num_classes)
-        return hops.CrossEntropy2d.apply(self.model(batch["image"].to(self.device)), mask.contiguous(), 255)
+        return self._segmentation_loss(batch["image"].to(self.device), mask.contiguous())
 
     @torch.no_grad()
     def validate(self, epoch=None):

@@ -289,6 +289,54 @@ def test_ce2d_vs_torch():
     close(ld.grad, lr.grad, rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("C", [3, 19])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_upsample_cross_entropy_fused_vs_torch(C, dtype):
+    """CrossEntropyLoss(ignore_index=255)(F.interpolate(low, bilinear), target) and its gradient with respect to the low-resolution
+    logits from ONE pass over the labels (am_upsample_ce2d_*): against torch-CPU fp32 on the same (dtype-rounded) logits, against
+    the two-op sequence (BilinearUp -> CrossEntropy2d), run twice for bit-identical results (no atomics on the gradient), on a
+    non-integer scale, the experts' 23x40 -> 720x1280 geometry, a padded pixel stride, and an all-ignored target (nan as torch)."""
+    from self_driving_model_amd.hip import ops as hops
+    g = torch.Generator().manual_seed(90 + C)
+    for (B, h, w, H, W, ld) in [(2, 5, 7, 37, 50, C), (3, 4, 9, 128, 288, 32), (2, 23, 40, 720, 1280, 32 if C > 3 else 8)]:
+        low = (torch.randn(B, C, h, w, generator=g) * 2).to(dtype).float()
+        tgt = torch.randint(0, C, (B, H, W), generator=g)
+        tgt[torch.rand(B, H, W, generator=g) < 0.15] = 255
+        lr = low.clone().requires_grad_()
+        loss_r = F.cross_entropy(F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=False), tgt, ignore_index=255)
+        (loss_r * 1.3).backward()
+        ref_grad = lr.grad.permute(0, 2, 3, 1)
+        ls = 64.0 if dtype == torch.float16 else 1.0
+
+        def run(fused):
+            lowd = torch.zeros(B, h, w, ld, dtype=dtype, device=_dev())
+            lowd[..., :C] = low.permute(0, 2, 3, 1).to(dtype).to(_dev())
+            lowd.requires_grad_()
+            if fused:
+                loss = hops.UpsampleCrossEntropy.apply(lowd, tgt.to(_dev()), C, H, W, 255, ls)
+            else:
+                loss = hops.CrossEntropy2d.apply(hops.BilinearUp.apply(lowd, C, H, W, ls), tgt.to(_dev()), 255)
+            (loss * 1.3).backward()
+            torch.cuda.synchronize()
+            return loss.detach(), lowd.grad.float() / ls
+
+        loss, grad = run(True)
+        close(loss, loss_r, rtol=1e-5, atol=1e-6)
+        if dtype == torch.float32:
+            close(grad[..., :C], ref_grad, rtol=1e-3, atol=1e-7)
+        else:  # the f16 gradient tensor carries 11 bits
+            assert rel_err(grad[..., :C], ref_grad) < 1e-3
+        assert float(grad[..., C:].abs().sum()) == 0.0
+        loss2, grad2 = run(True)
+        assert torch.equal(grad, grad2), "fused gradient is not deterministic"
+        loss_u, grad_u = run(False)
+        close(loss, loss_u, rtol=1e-5, atol=1e-6)
+        assert rel_err(grad, grad_u) < (1e-5 if dtype == torch.float32 else 1e-3)
+    tgt_all = torch.full((1, 16, 24), 255, dtype=torch.int64)
+    lowd = torch.randn(1, 2, 3, C, device=_dev()).to(dtype).requires_grad_()
+    assert torch.isnan(hops.UpsampleCrossEntropy.apply(lowd, tgt_all.to(_dev()), C, 16, 24, 255, 1.0))
+
+
 def test_mlp_tail_ops_vs_torch():
     import torch.nn as nn
     from self_driving_model_amd.hip import ops as hops

@@ -1039,6 +1039,40 @@ def test_bdd_trainer_hipgraph_matches_eager(task):
             assert torch.equal(finals[True][1][k], v), k  # num_batches_tracked
 
 
+@pytest.mark.parametrize("task,ncls", [("drivable", 3), ("segmentation", 19)])
+def test_bdd_trainer_fused_segmentation_loss_matches_two_op_sequence(task, ncls):
+    """BDDTrainer's dense-expert loss (train_bdd100k_ddp.py:89-100 criterion(model(images), masks)) runs fused on the low-resolution
+    logits (pixel_ce_loss -> am_upsample_ce2d_*); the same step with FUSE_SEG_LOSS off (model.forward -> CrossEntropy2d) must give
+    the same loss and the same gradient buffer.  fp32 mode, one eager step from identical weights."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.experts import BDDDrivableExpert, BDDSegmentationExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training import train_bdd100k_ddp as tb
+    dev = _dev()
+    H, W = 96, 160
+    res = {}
+    with runtime.precision(torch.float32):
+        for fused in (True, False):
+            torch.manual_seed(21)
+            cls = BDDDrivableExpert if task == "drivable" else BDDSegmentationExpert
+            m = cls(ncls, pretrained_backbone=False).to(dev).train()
+            b = synthetic.bdd_drivable_batch(4, H, W, ncls, dev, seed=5)
+            loader = synthetic.SyntheticLoader(b, 2)
+            tr = tb.BDDTrainer(task, m, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t", "use_graph": False})
+            old = tb.FUSE_SEG_LOSS
+            tb.FUSE_SEG_LOSS = fused
+            try:
+                with tr._step_stream:
+                    loss = tr._fwd_bwd(b)
+                torch.cuda.synchronize()
+                res[fused] = (float(loss), tr.optimizer.flat_g.detach().clone())
+            finally:
+                tb.FUSE_SEG_LOSS = old
+            del loss
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    assert rel_err(res[True][1], res[False][1]) < 1e-3
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_eval_bn_fold_follows_training(use_graph):
     """The eval-mode conv+BatchNorm fold (hip/conv.py FOLD_EVAL_BN) is a cache of the weights AND the running statistics.
