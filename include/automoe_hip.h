@@ -132,16 +132,13 @@ int am_conv_last_variant(void);
  *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k.
  *   AM_TUNE_WGRAD_MAX_SLABS   am_conv_wgrad_ws keeps one slab per pixel chunk up to this many chunks; beyond it the chunks add
  *                  atomically into ONE zero-filled slab (0: always; a huge value: never).
- *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256;
- *   AM_TUNE_DEV            kernel-development switches (scratch/ab_*.py timing experiments: parts of a kernel compiled in but
- *                          skipped); 0 in production, results are wrong otherwise. */
+ *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256. */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
 #define AM_TUNE_WGRAD_MAX_SLABS 3
 #define AM_TUNE_RING_SHORT_K 4
-#define AM_TUNE_DEV 5
-#define AM_TUNE_COUNT 6
+#define AM_TUNE_COUNT 5
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 

@@ -1,4 +1,4 @@
-"""First-layer (stem) weight gradient: plain vs fused-BatchNorm-backward form, with development switches (tuning key 5)."""
+"""First-layer (stem) weight gradient: plain vs fused-BatchNorm-backward form, (round 2: 4 waves / transform at load time 295 / 688 us at B=16 -> 8 waves, transform at store time, taps split over waves 206 / 448 us; ~90 us of either is the final fp32-atomic flush)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,4 @@ def t(f, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 plain = lambda: L.am_conv_wgrad(ctypes.byref(g), hc.dt_code(dt), hc.ptr(x), hc.ptr(dy), 1.0, hc.ptr(dwp), hc.stream())
 bnf = lambda: L.am_conv_wgrad_bn(ctypes.byref(g), hc.dt_code(dt), hc.ptr(x), hc.ptr(dy), hc.ptr(y), hc.ptr(raw), hc.ptr(mean), hc.ptr(rstd), hc.ptr(coef), 1, 1.0, hc.ptr(dwp), hc.stream())
-for dbg in (0, 1, 2, 3):
-    L.am_set_tuning(5, dbg)
-    print(f"B={B} dbg={dbg} (1: no flush, 2: no raw/yout loads + transform)  plain {t(plain):7.1f} us   fused-BN {t(bnf):7.1f} us", flush=True)
-L.am_set_tuning(5, 0)
+print(f"B={B}  plain {t(plain):7.1f} us   fused-BN {t(bnf):7.1f} us", flush=True)

@@ -622,7 +622,6 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_WGRAD_RING */ 1,
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,
     /* AM_TUNE_RING_SHORT_K */ 8,
-    /* AM_TUNE_DEV */ 0,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }

@@ -7,7 +7,11 @@
 // stages each tile's dY block and its input patch ONCE in LDS and accumulates the whole [N][taps*64] gradient in
 // registers (pixels are the MFMA reduction dimension: both operands are pixel-major, so fragments come from the
 // ds_read_b64_tr_b16 hardware-transpose read, LDS pitches = 64 mod 128 bytes); one flush per workgroup at the end
-// (LDS reduction across the four waves, then fp32 atomics).
+// (LDS reduction across the waves of a channel block, then fp32 atomics).
+// One workgroup of EIGHT waves per CU (two per SIMD, 128 accumulator registers each): the next tile's global loads -- dY and,
+// in the fused-BatchNorm form, the conv output and the ReLU mask, 14 x 16 B per thread -- are issued before the MFMA phase and
+// consumed after it (the BatchNorm-backward transform runs when the tile is stored to LDS), so ~115 KB per CU are in flight
+// under the MFMAs.  (Four waves with the transform at load time ran the fused form at 2.5 TB/s: 688 us for the stem at B = 16.)
 #include "am_common.h"
 
 namespace amw {
@@ -29,7 +33,6 @@ struct S2dWgradParams {
   const void* yout;  // BN+ReLU output (ReLU mask), NULL without ReLU
   const float* mean; const float* rstd; const float* coef;  // coef = [3][N] from am_bn_bwd_finalize
   int relu;
-  int dbg;
 };
 
 typedef __attribute__((address_space(3))) s4v* lds_s4v;
@@ -41,18 +44,24 @@ __device__ __forceinline__ half8_t tr_frag(const char* lo_addr, int hi_delta) {
   return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
 }
 
-// NT = number of 32-channel blocks of dY (1: N <= 32, 2: N <= 64).  Wave w: NT == 1 -> tile rows 2w, 2w+1; NT == 2 ->
-// channel block w & 1, tile rows 4*(w>>1) .. +3.
+// NT = number of 32-channel blocks of dY (1: N <= 32, 2: N <= 64).  Wave w of 8: NT == 1 -> tile row w; NT == 2 ->
+// channel block w & 1, then tap group, then row group (see TSP below).
 template <int TAPS, int NT, bool BNF>
-__global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) {
+__global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) {
+  constexpr int NTH = 512;
   constexpr int PH = TH + TAPS - 1;
   constexpr int PATCH_PIX = PH * PW;
   constexpr int PATCH_BYTES = PATCH_PIX * PPITCH;
   constexpr int DYB = NT * 64;                      // dY bytes per pixel in LDS (32 channels per block)
   constexpr int PDY = NT == 1 ? 64 : 192;           // pitch = 64 (mod 128)
-  constexpr int PCH = (PATCH_PIX * 2 + 255) / 256;  // patch 16-byte chunks per thread
-  constexpr int DCH = TH * TW * (DYB / 16) / 256;   // dY chunks per thread
-  constexpr int ROWS = NT == 1 ? 2 : 4;             // tile rows per wave
+  constexpr int PCH = (PATCH_PIX * 2 + NTH - 1) / NTH;  // patch 16-byte chunks per thread
+  constexpr int DCH = TH * TW * (DYB / 16) / NTH;       // dY chunks per thread
+  // eight waves = NT channel blocks x TSP tap groups x row groups: the stem (4x4 taps, 64 channels) splits its taps over two
+  // waves, which halves the accumulator registers (64 instead of 128: no spills next to 14 loads in flight -- a spill reload
+  // costs an s_waitcnt vmcnt(0), i.e. the whole prefetch)
+  constexpr int TSP = (NT == 2 && TAPS % 2 == 0) ? 2 : 1;
+  constexpr int TPW = TAPS / TSP;                       // taps (patch rows) per wave
+  constexpr int ROWS = TH / (8 / (NT * TSP));           // tile rows per wave
   constexpr int KTOT = TAPS * 64;
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -64,31 +73,29 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
   const int nblk = NT == 1 ? 0 : (wid & 1);
-  const int row0 = NT == 1 ? 2 * wid : 4 * (wid >> 1);
+  const int tap0 = NT == 1 ? 0 : ((wid >> 1) % TSP) * TPW;
+  const int row0 = (NT == 1 ? wid : wid / (2 * TSP)) * ROWS;
 
-  f32x16 acc[TAPS][2];
+  f32x16 acc[TPW][2];
 #pragma unroll
-  for (int i = 0; i < TAPS; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jp][r] = 0.f;
 
-  // BNF: this thread always loads the same 8-channel chunk of a pixel (256 threads, 4 or 8 chunks per pixel)
-  float bn_mu[8], bn_rs[8], bn_c0[8], bn_c1[8], bn_c2[8];
+  // BNF: per-channel constants in LDS ([5][64]: mean, rstd, coef0..2); a thread always handles the same 8-channel chunk
+  float* bnc = reinterpret_cast<float*>(dYs + TH * TW * PDY);
   if constexpr (BNF) {
-    const int c0 = (tid % (DYB / 16)) * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = min(c0 + e, p.N - 1);
-      bn_mu[e] = p.mean[c]; bn_rs[e] = p.rstd[c];
-      bn_c0[e] = p.coef[c]; bn_c1[e] = p.coef[p.N + c]; bn_c2[e] = p.coef[2 * p.N + c];
+    for (int i = tid; i < 5 * 64; i += NTH) {
+      const int c = min(i & 63, p.N - 1), f = i >> 6;
+      bnc[i] = f == 0 ? p.mean[c] : f == 1 ? p.rstd[c] : p.coef[(f - 2) * p.N + c];
     }
   }
   const half_t* __restrict__ raw = static_cast<const half_t*>(p.raw);
   const half_t* __restrict__ yout = static_cast<const half_t*>(p.yout);
 
-  uint4 rp[PCH], rd[DCH];
+  uint4 rp[PCH], rd[DCH], rx[BNF ? DCH : 1], ry[BNF ? DCH : 1];
   auto load_tile = [&](int tile) {
     const int img = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - img * (p.tiles_y * p.tiles_x);
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
     const int iy0 = ty * TH + p.off0, ix0 = tx * TW + p.off0;
 #pragma unroll
     for (int k = 0; k < PCH; ++k) {
-      const int c = tid + k * 256;
+      const int c = tid + k * NTH;
       const int pidx = c >> 1;
       const int prow = pidx / PW, pcol = pidx - prow * PW;
       const int iy = iy0 + prow, ix = ix0 + pcol;
@@ -107,43 +114,49 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
     }
 #pragma unroll
     for (int k = 0; k < DCH; ++k) {
-      const int c = tid + k * 256;
+      const int c = tid + k * NTH;
       const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
       const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u), xr = v, yr = v;
       if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff) {
         const long long off = ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8;
         v = *reinterpret_cast<const uint4*>(dy + off);
-        if (BNF && !(p.dbg & 2)) {
-          const uint4 xr = *reinterpret_cast<const uint4*>(raw + off);
-          uint4 yr = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (BNF) {
+          xr = *reinterpret_cast<const uint4*>(raw + off);
           if (p.relu) yr = *reinterpret_cast<const uint4*>(yout + off);
-          const half8_t gv = __builtin_bit_cast(half8_t, v), xv = __builtin_bit_cast(half8_t, xr), yv = __builtin_bit_cast(half8_t, yr);
-          half8_t o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float dz = (float)gv[e];
-            if (p.relu && !((float)yv[e] > 0.f)) dz = 0.f;
-            const float xhat = ((float)xv[e] - bn_mu[e]) * bn_rs[e];
-            o[e] = cc * 8 + e < p.N ? (half_t)(bn_c0[e] * (dz - bn_c1[e] - xhat * bn_c2[e])) : (half_t)0.f;
-          }
-          v = __builtin_bit_cast(uint4, o);
         }
       }
       rd[k] = v;
+      if constexpr (BNF) { rx[k] = xr; ry[k] = yr; }
     }
+  };
+  // the gradient w.r.t. the conv output from (dY, conv output, ReLU mask): bn.hip bn_bwd_apply_k's arithmetic
+  auto bn_transform = [&](uint4 v, uint4 xr, uint4 yr, int cc) -> uint4 {
+    const half8_t gv = __builtin_bit_cast(half8_t, v), xv = __builtin_bit_cast(half8_t, xr), yv = __builtin_bit_cast(half8_t, yr);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cc * 8 + e;
+      float dz = (float)gv[e];
+      if (p.relu && !((float)yv[e] > 0.f)) dz = 0.f;
+      const float xhat = ((float)xv[e] - bnc[c]) * bnc[64 + c];
+      o[e] = c < p.N ? (half_t)(bnc[128 + c] * (dz - bnc[192 + c] - xhat * bnc[256 + c])) : (half_t)0.f;
+    }
+    return __builtin_bit_cast(uint4, o);
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int k = 0; k < PCH; ++k) {
-      const int c = tid + k * 256;
+      const int c = tid + k * NTH;
       if ((c >> 1) < PATCH_PIX) *reinterpret_cast<uint4*>(patch + (c >> 1) * PPITCH + (c & 1) * 16) = rp[k];
     }
 #pragma unroll
     for (int k = 0; k < DCH; ++k) {
-      const int c = tid + k * 256;
+      const int c = tid + k * NTH;
       const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
-      *reinterpret_cast<uint4*>(dYs + pix * PDY + cc * 16) = rd[k];
+      uint4 v = rd[k];
+      if constexpr (BNF) v = bn_transform(v, rx[k], ry[k], cc);
+      *reinterpret_cast<uint4*>(dYs + pix * PDY + cc * 16) = v;
     }
   };
 
@@ -164,34 +177,39 @@ __global__ __launch_bounds__(256) void conv_s2d_wgrad_k(const S2dWgradParams p) 
         const int px = xh * 16 + 8 * (gq >> 1) + q;
         const half8_t a = tr_frag(dYs + (row * TW + px) * PDY + nblk * 64 + ((gq & 1) * 16 + 4 * pp) * 2, 4 * PDY);
 #pragma unroll
-        for (int i = 0; i < TAPS; ++i)
+        for (int i = 0; i < TPW; ++i)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             // 32 gradient columns = the 16 channels of run pixels 2*jp and 2*jp + 1 (the 16-lane group picks the pixel)
-            const half8_t b = tr_frag(patch + ((row + i) * PW + px + 2 * jp + (gq & 1)) * PPITCH + pp * 8, 4 * PPITCH);
+            const half8_t b = tr_frag(patch + ((row + tap0 + i) * PW + px + 2 * jp + (gq & 1)) * PPITCH + pp * 8, 4 * PPITCH);
             acc[i][jp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][jp], 0, 0, 0);
           }
       }
     }
   }
 
-  if (p.dbg & 1) return;
   // ---- flush: waves that share a channel block add up in LDS, then one fp32 atomic per element per workgroup ----
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);  // [NT][32][KTOT]
-  for (int e = tid; e < NT * 32 * KTOT; e += 256) red[e] = 0.f;
+  for (int e = tid; e < NT * 32 * KTOT; e += NTH) red[e] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < TAPS; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        atomicAdd(red + (nblk * 32 + n) * KTOT + i * 64 + jp * 32 + (lane & 31), acc[i][jp][r]);
+        atomicAdd(red + (nblk * 32 + n) * KTOT + (tap0 + i) * 64 + jp * 32 + (lane & 31), acc[i][jp][r]);
       }
   __syncthreads();
-  for (int e = tid; e < NT * 32 * KTOT; e += 256) {
+  // every workgroup finishes at about the same time: each starts its pass over dW at a different row, so they do not all hit
+  // the same addresses together
+  constexpr int TOT = NT * 32 * KTOT;
+  const int rot = (int)((blockIdx.x * 37u) % (unsigned)(NT * 32)) * KTOT;
+  for (int e0 = tid; e0 < TOT; e0 += NTH) {
+    int e = e0 + rot;
+    e = e >= TOT ? e - TOT : e;
     const int n = e / KTOT;
     if (n < p.N) atomicAdd(p.dw + (size_t)n * KTOT + (e - n * KTOT), red[e] * p.scale);
   }
@@ -203,7 +221,7 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int PATCH = ((PH * PW * PPITCH + 1023) / 1024) * 1024;
   constexpr int DYS = TH * TW * (NT == 1 ? 64 : 192);
   constexpr int RED = NT * 32 * TAPS * 64 * 4;
-  constexpr int LDS = (PATCH + DYS) > RED ? (PATCH + DYS) : RED;
+  constexpr int LDS = (PATCH + DYS + 5 * 64 * 4) > RED ? (PATCH + DYS + 5 * 64 * 4) : RED;
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (LDS > 64 * 1024 && !attr_done) {
@@ -211,9 +229,9 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
-  const int grid = p.ntiles < 512 ? p.ntiles : 512;  // persistent: two workgroups per CU
+  const int grid = p.ntiles < 256 ? p.ntiles : 256;  // persistent: one 8-wave workgroup per CU
   g_am_conv_variant = AM_CV_WGRAD_S2D;
-  hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT, BNF>), dim3(grid), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((conv_s2d_wgrad_k<TAPS, NT, BNF>), dim3(grid), dim3(512), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -241,7 +259,6 @@ int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, 
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
   p.raw = raw; p.yout = yout; p.mean = mean; p.rstd = rstd; p.coef = coef; p.relu = relu;
-  p.dbg = am_tuning(AM_TUNE_DEV);
   if (raw != nullptr) {
     if (!mean || !rstd || !coef || (relu && !yout)) return AM_ERR_ARG;
     if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, true>(p, s) : launch<4, 1, true>(p, s);
