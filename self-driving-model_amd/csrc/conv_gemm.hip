@@ -622,6 +622,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_WGRAD_RING */ 1,
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,
     /* AM_TUNE_RING_SHORT_K */ 8,
+    /* AM_TUNE_HALO_MIN_TILES */ 256,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }
@@ -637,6 +638,9 @@ extern "C" int am_get_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ?
 
 int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                      double* stats, hipStream_t s);  // conv_ring.hip
+
+int am_conv_halo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                     double* stats, hipStream_t s);  // conv_halo.hip
 
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;
@@ -671,6 +675,9 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 64->64 3x3 layers: weights-stationary patch kernel (per-CU load bandwidth is the bound of the gather form there)
     rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, nullptr, y, stats, s);
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+    // 3x3 / stride-1 layers with 64 < N <= 128 (layer2 and its dgrad): halo-staged patch instead of nine gathers
+    rc = am_conv_halo_f16(g, x, w, bias, relu, nullptr, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads
     // into 64 channels) stays on the register-staged kernel
@@ -782,6 +789,8 @@ extern "C" int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x,
   if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, res, y, nullptr, s);
+  if (rc != AM_ERR_UNSUPPORTED) return rc;
+  rc = am_conv_halo_f16(g, x, w, bias, relu, res, y, nullptr, s);
   if (rc != AM_ERR_UNSUPPORTED) return rc;
   return am_conv_ring_f16(g, x, w, bias, relu, res, y, nullptr, s);
 }

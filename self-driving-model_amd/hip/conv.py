@@ -337,9 +337,9 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
-CONV_KERNEL_NAMES = {1: "conv_ring_k<256,256,2,4>", 2: "conv_ring_k<256,128,4,2>", 3: "conv3x3_c64n64_duo_k", 4: "conv3x3_c64n64_wreg_k",
-                     5: "conv3x3_c64n64_k", 6: "conv_gemm2_k", 7: "conv_gemm3_k", 8: "conv_gemm_k", 9: "conv_s2d_k", 10: "conv_s2d_pool_k",
-                     11: "conv_ring16_k<256,256,2,4>", 12: "conv_ring16_k<256,128,4,2>"}
+CONV_KERNEL_NAMES = {1: "conv_ring_k<256,256,2,4>", 2: "conv_ring_k<256,128,4,2>", 3: "conv3x3_c64n64_duo_k", 6: "conv_gemm2_k", 8: "conv_gemm_k",
+                     9: "conv_s2d_k", 10: "conv_s2d_pool_k", 11: "conv_ring16_k<256,256,2,4>", 12: "conv_ring16_k<256,128,4,2>",
+                     16: "conv_halo_k"}
 
 
 def _timed(kind: str, flops: float, fn):

@@ -475,6 +475,74 @@ def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
     np.testing.assert_allclose(st[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
 
 
+@pytest.mark.parametrize("case", [(128, 128, 2, 90, 160), (64, 128, 3, 37, 50), (128, 96, 2, 41, 77), (256, 128, 1, 64, 96)])
+def test_conv_halo_kernel_vs_torch_and_ring_kernel(case):
+    """3x3 / stride-1 layers with 64 < N <= 128 (ResNet layer2 and its input gradient): the halo-staged kernel conv_halo_k
+    (conv_halo.hip; forced here for small grids through AM_TUNE_HALO_MIN_TILES) against torch and, bit for bit in the output
+    and to fp64 rounding in the statistics, against the gather kernels it replaces.  Edge tiles in both directions (the
+    BatchNorm statistics must exclude tile pixels outside the image), Cin of 2 / 4 / 8 chunks, N below the tile width, the
+    input-gradient geometry (dgrad_plans + pack_dgrad), bias + ReLU and residual epilogues."""
+    import ctypes
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import lib
+    L = lib.get()
+    cin, cout, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).half().float()
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g).half().float()
+    s = hc.ConvSpec(cin, cout, 3, 1, 1)
+    ldo = hc.channel_ld(cout, 2)
+    geom = hc.fwd_geom(s, B, H, W, cin, ldo, 2)
+    xd, wp = nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16)
+    yr = F.conv2d(x, w, padding=1)
+    outs = {}
+    for min_tiles, kernel in ((1, "conv_halo_k"), (1 << 30, None)):
+        old = L.am_set_tuning(lib.AM_TUNE_HALO_MIN_TILES, min_tiles)
+        try:
+            y = torch.zeros(B, H, W, ldo, dtype=torch.float16, device=_dev())
+            stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
+            hc.conv_gemm(geom, xd, wp, None, False, y, stats)
+            name = launched_kernel(kernel, what=f"halo {case}")
+            assert kernel is not None or name != "conv_halo_k"
+            y2 = torch.zeros_like(y)
+            hc.conv_gemm(geom, xd, wp, b.to(_dev()), True, y2, None)
+            y3 = torch.zeros_like(y)
+            if ldo == cout:
+                try:
+                    L.am_conv_gemm_res(ctypes.byref(geom), hc.dt_code(torch.float16), hc.ptr(xd), hc.ptr(wp), hc.ptr(b.to(_dev())),
+                                       hc.ptr(nhwc(r, torch.float16)), 1, hc.ptr(y3), hc.stream())
+                except RuntimeError as e:  # the gather kernels decline small grids: only the halo run is checked then
+                    assert "UNSUPPORTED" in str(e) and kernel is None
+                    y3 = None
+            # input gradient of the same layer: dX = conv(dY, flipped weights), the stride-1 plan has the forward geometry
+            (gd, taps), = hc.dgrad_plans(s, B, H, W, cin, ldo, 2)
+            dyd = nhwc(r, torch.float16, ld=ldo)
+            dx = torch.zeros(B, H, W, cin, dtype=torch.float16, device=_dev())
+            hc.conv_gemm(gd, dyd, hc.pack_dgrad(w.to(_dev()), taps, torch.float16, ldo), None, False, dx, None)
+            dg_name = launched_kernel(None, what=f"halo dgrad {case}")
+            torch.cuda.synchronize()
+            outs[min_tiles] = (y, stats.view(16, 2, cout).sum(0).cpu(), y2, y3, dx, dg_name)
+        finally:
+            L.am_set_tuning(lib.AM_TUNE_HALO_MIN_TILES, old)
+    y, st, y2, y3, dx, dg_name = outs[1]
+    assert (dg_name == "conv_halo_k") == (64 < cin <= 128), dg_name  # the dgrad's N is the layer's Cin
+    close(nchw(y, cout), yr, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(st[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=0.5)
+    np.testing.assert_allclose(st[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
+    close(nchw(y2, cout), F.relu(yr + b.view(1, -1, 1, 1)), rtol=3e-3, atol=3e-3)
+    if y3 is not None:
+        close(nchw(y3, cout), F.relu(yr + b.view(1, -1, 1, 1) + r), rtol=3e-3, atol=4e-3)
+    dxr = F.conv_transpose2d(r, w, padding=1)
+    close(nchw(dx, cin), dxr, rtol=3e-3, atol=3e-3)
+    # same products, same fp32 accumulation order over K (tap-major inside a chunk vs chunk-major inside a tap differ): close, not equal
+    yo, sto, y2o, y3o, dxo, _ = outs[1 << 30]
+    assert rel_err(y, yo) < 2e-3 and rel_err(dx, dxo) < 2e-3
+    np.testing.assert_allclose(st.numpy(), sto.numpy(), rtol=1e-4, atol=0.05)
+    assert float(y[..., cout:].abs().sum()) == 0.0  # pad channels of the pixel stride stay zero
+
+
 @pytest.mark.parametrize("spec", [(64, 7, 3), (32, 5, 2)])
 def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
     """Large first-layer problems run the weights-stationary s2d kernel (conv_s2d.hip).  Mode 0 (raw + statistics) is
