@@ -103,7 +103,8 @@ int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* 
  * output never goes through HBM (ResNet BasicBlock conv1 -> bn1 -> relu -> conv2 with nothing else reading the middle tensor,
  * torchvision resnet.py BasicBlock.forward as used by bdd_*_expert.py:9-11).  Zero padding applies to the transformed tensor.
  * No bias / ReLU epilogue; `stats` as in am_conv_gemm.  Returns AM_ERR_UNSUPPORTED unless the layer is a dense 3x3 / stride 1 /
- * pad 1, 64 -> 64 f16 convolution large enough for the weights-in-registers kernel (caller: am_bn_apply + am_conv_gemm). */
+ * pad 1 f16 convolution whose kernel stages an input patch in LDS: 64 -> 64 (weights-in-registers kernel) or Cin <= 256 ->
+ * 64 < N <= 128 (halo-staged kernel), large enough for it (caller: am_bn_apply + am_conv_gemm). */
 int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
                        const void* w, void* y, double* stats, am_stream_t stream);
 

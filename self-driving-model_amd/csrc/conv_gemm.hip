@@ -641,6 +641,8 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
 
 int am_conv_halo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                      double* stats, hipStream_t s);  // conv_halo.hip
+int am_conv_halo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                         const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s);  // conv_halo.hip
 
 extern "C" int am_conv_npad(int N) {
   if (N > 64) return am_cdiv(N, 128) * 128;
@@ -801,7 +803,9 @@ extern "C" int am_conv_gemm_prebn(const am_conv_geom* g, int dtype, const void* 
   if (rc != AM_OK) return rc;
   if (!x || !w || !y || !pre_scale || !pre_shift) return AM_ERR_ARG;
   if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
-  return am_conv3x3_c64n64_duo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, nullptr, y, stats, static_cast<hipStream_t>(stream));
+  rc = am_conv3x3_c64n64_duo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, nullptr, y, stats, static_cast<hipStream_t>(stream));
+  if (rc != AM_ERR_UNSUPPORTED) return rc;
+  return am_conv_halo_pre_f16(g, x, pre_scale, pre_shift, w, nullptr, 0, nullptr, y, stats, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,

@@ -16,6 +16,11 @@
 // The LDS-DMA destination is lane-linear, so lane j of piece i owns 16-byte granule 64 i + j = (pixel g / 5, chunk g % 5);
 // chunk 4 is the pad (requested out of range).  Weights: three 8 KB stages exactly as conv_ring_k (64-byte rows, XOR swizzle).
 // 78 KB of LDS + an 80 KB epilogue alias: two workgroups per CU.
+//
+// PRE (am_conv_gemm_prebn): the convolution runs on relu(x * pre_scale[c] + pre_shift[c]) -- the BatchNorm + ReLU of the
+// producing layer (bn.hip bn_apply_k's fp32 arithmetic) -- applied to the staged patch, once per element instead of once per
+// tap: every wave rewrites the 16-byte granules its own DMA pieces delivered, one K-step before the chunk's first use.  Pixels
+// outside the image stay zero (the padding applies to the transformed tensor).
 #include "am_common.h"
 
 namespace amh {
@@ -32,9 +37,11 @@ constexpr int BKB = 64, BSTAGE = BN * BKB, NSTG = 3;
 constexpr int PSLOTS = 4;                 // K-steps of a chunk on which a wave issues one patch piece (8 waves x 4 >= 27)
 constexpr int B_BASE = 2 * PATCH_BYTES;   // weight ring behind the two patch buffers
 constexpr int RING_BYTES = B_BASE + NSTG * BSTAGE;
+constexpr int MAX_PRE_C = 256;            // input channels of the PRE form (scale / shift table behind the ring)
+constexpr int AFF_BASE = RING_BYTES;
 constexpr int SP = TN * 64 + 16;          // epilogue staging pitch per output pixel
 constexpr int EPI_BYTES = 8192 + NW * (TM * 32) * SP;
-constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+constexpr int LDS_BYTES = (RING_BYTES + 2 * MAX_PRE_C * 4) > EPI_BYTES ? (RING_BYTES + 2 * MAX_PRE_C * 4) : EPI_BYTES;
 constexpr unsigned OOB = 0x80000000u;
 static_assert(NW * PSLOTS >= NPIECE && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
@@ -48,6 +55,8 @@ struct HaloParams {
   int B, H, W, ldi, x_coff, ldo, y_coff, Cin, N, relu;
   int tiles_y, tiles_x, ntiles, nchunk;
   unsigned x_bytes, w_bytes;
+  const float* pre_scale;  // PRE: [Cin] each
+  const float* pre_shift;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -57,6 +66,7 @@ __device__ __forceinline__ void buffer_to_lds16(const void* base, unsigned bytes
                                            (lds_ptr)dst, 16, voff, soff, 0, 0);
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
   typedef half_t T;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -72,14 +82,16 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
   const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
 
   // ---- loader state ----
-  // patch: slot s of this wave is piece (s * 8 + wid) % 27 (the five wrapped pieces are fetched twice: same bytes, same place;
-  // every wave then issues the same number of pieces per K-step, which the counted vmcnt waits rely on)
+  // patch: slot s of this wave is piece s * 8 + wid; the last slot has only three pieces left, waves 3..7 fetch their OWN slot-0
+  // piece again (same bytes, same place, same wave: nothing races), so every wave issues the same number of pieces per K-step,
+  // which the counted vmcnt waits rely on
   unsigned pvo[PSLOTS];
   int pdst[PSLOTS];
+  int pcc = 0;  // 2 bits per slot: the 16-byte channel chunk of this lane's granule (PRE)
 #pragma unroll
   for (int s = 0; s < PSLOTS; ++s) {
     int piece = s * 8 + wid;
-    piece = piece >= NPIECE ? piece - NPIECE : piece;
+    piece = piece >= NPIECE ? wid : piece;
     const int gidx = piece * 64 + lane;
     const int pix = (int)__umulhi((unsigned)gidx, 0x33333334u);  // gidx / 5 (exact below 2^30)
     const int cc = gidx - pix * 5;
@@ -88,7 +100,9 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
     const bool ok = cc < 4 && pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     pvo[s] = ok ? (unsigned)((((img * p.H + iy) * p.W + ix) * p.ldi + p.x_coff) * 2 + cc * 16) : OOB;
     pdst[s] = piece * 1024;
+    pcc |= (cc & 3) << (2 * s);
   }
+  const int own_slots = wid < NPIECE - 8 * (PSLOTS - 1) ? PSLOTS : PSLOTS - 1;  // slots whose piece this wave transforms (PRE)
   // weights: this wave's 16 rows of the 128-row tile, one piece per K-step
   const int lrow = lane >> 2, cpos = lane & 3;
   const int brow = wid * 16 + lrow;
@@ -110,6 +124,35 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
   issue_b(0, 0, 0);
   issue_b(1, 0, 1);
 
+  // PRE: relu(x * scale + shift) on this wave's granules of the patch of `chunk` in buffer `buf` (after the wave's own vmcnt
+  // wait, before the barrier that publishes the patch); out-of-image granules stay zero
+  float* aff = reinterpret_cast<float*>(smem + AFF_BASE);  // [2][MAX_PRE_C]
+  auto transform = [&](int chunk, int buf) {
+#pragma unroll
+    for (int s = 0; s < PSLOTS; ++s) {
+      if (s < own_slots && pvo[s] != OOB) {
+        half8_t* slot = reinterpret_cast<half8_t*>(smem + buf * PATCH_BYTES + pdst[s] + lane * 16);
+        const int c0 = chunk * 32 + ((pcc >> (2 * s)) & 3) * 8;
+        const half8_t v = *slot;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + c0), s1 = *reinterpret_cast<const f32x4*>(aff + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + MAX_PRE_C + c0), h1 = *reinterpret_cast<const f32x4*>(aff + MAX_PRE_C + c0 + 4);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (half_t)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
+          o[4 + e] = (half_t)fmaxf((float)v[4 + e] * s1[e] + h1[e], 0.f);
+        }
+        *slot = o;
+      }
+    }
+  };
+  if (PRE) {
+    for (int i = tid; i < p.Cin; i += NTH) {
+      aff[i] = p.pre_scale[i];
+      aff[MAX_PRE_C + i] = p.pre_shift[i];
+    }
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -127,6 +170,13 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
 
   half8_t a0[TM], b0[TN], a1[TM], b1[TN];
   asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // patch 0 and weight tile 0 landed (tile 1 may be in flight)
+  if (PRE) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the scale / shift table is in LDS
+    asm volatile("" ::: "memory");
+    transform(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -150,6 +200,11 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
       for (int tn = 0; tn < TN; ++tn) b1[tn] = *reinterpret_cast<const half8_t*>(smem + fb[1] + stage * BSTAGE + tn * 32 * BKB);
       // weight tile kk+2 into the stage of tile kk-1 (everyone finished reading it before the last barrier); patch piece of the
       // next chunk into the other patch buffer (last read during the previous chunk)
+      if (PRE && t == 7) {
+        // the next chunk's patch pieces were issued on taps 0..3; only the weight pieces of taps 4..6 are newer
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (c + 1 < nchunk) transform(c + 1, (c + 1) & 1);  // published by this K-step's barrier, first read after the next one
+      }
       if (t + 2 < 9) issue_b(t + 2, c, istage);
       else issue_b(t + 2 - 9, c + 1, istage);
       if (t < PSLOTS) issue_patch(t, c + 1, (c + 1) & 1);
@@ -311,9 +366,20 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
 
 // Returns AM_ERR_UNSUPPORTED unless the geometry is a dense 3x3 / stride 1 / pad 1 convolution (canonical tap order, as
 // fwd_geom and the stride-1 dgrad plan produce it) with Cin a multiple of 32, 64 < N <= 128, f16, large enough to fill the chip.
+int am_conv_halo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                         const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s);
+
 int am_conv_halo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                      double* stats, hipStream_t s) {
+  return am_conv_halo_pre_f16(g, x, nullptr, nullptr, w, bias, relu, res, y, stats, s);
+}
+
+// pre_scale / pre_shift (both or neither, [Cin], Cin <= 256): the convolution runs on relu(x * pre_scale[c] + pre_shift[c]).
+int am_conv_halo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
+                         const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s) {
   using namespace amh;
+  const bool pre = pre_scale != nullptr;
+  if (pre && (g->krun > MAX_PRE_C || g->krun != g->ldi || g->x_coff != 0)) return AM_ERR_UNSUPPORTED;
   if (g->ntaps != 9 || g->pix_shift != 31 || g->N <= 64 || g->N > BN || g->krun % 32 != 0 || g->krun < 32 || g->osplit > 0) return AM_ERR_UNSUPPORTED;
   if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
   if (g->MH != g->IH || g->MW != g->IW || g->OH != g->IH || g->OW != g->IW) return AM_ERR_UNSUPPORTED;
@@ -338,14 +404,17 @@ int am_conv_halo_f16(const am_conv_geom* g, const void* x, const void* w, const 
   p.nchunk = g->krun / 32;
   p.x_bytes = (unsigned)x_bytes;
   p.w_bytes = (unsigned)w_bytes;
-  static bool attr_done_dev[AM_MAX_DEVICES] = {};
-  bool& attr_done = attr_done_dev[am_current_device()];
+  p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+  static bool attr_done_dev[AM_MAX_DEVICES][2] = {};
+  bool& attr_done = attr_done_dev[am_current_device()][pre ? 1 : 0];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return AM_ERR_LAUNCH;
+    const void* fn = pre ? reinterpret_cast<const void*>(conv_halo_k<true>) : reinterpret_cast<const void*>(conv_halo_k<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return AM_ERR_LAUNCH;
     attr_done = true;
   }
   g_am_conv_variant = AM_CV_HALO_256x128;
-  hipLaunchKernelGGL(conv_halo_k, dim3(p.ntiles), dim3(NTH), LDS_BYTES, s, p);
+  if (pre) hipLaunchKernelGGL(conv_halo_k<true>, dim3(p.ntiles), dim3(NTH), LDS_BYTES, s, p);
+  else hipLaunchKernelGGL(conv_halo_k<false>, dim3(p.ntiles), dim3(NTH), LDS_BYTES, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -696,46 +696,33 @@ FUSE_BLOCK_BN = True  # tests flip this to compare with the unfused sequence
 
 
 @torch.no_grad()
-def fused_basic_block_c64(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, cache2: PackedWeights):
-    """ResNet BasicBlock 64 -> 64 (stride 1, identity shortcut) of a FROZEN trunk in train-mode BatchNorm, f16:
+def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, cache2: PackedWeights):
+    """ResNet BasicBlock C -> C (stride 1, identity shortcut; C = 64: layer1, C = 128: layer2) of a FROZEN trunk in train-mode
+    BatchNorm, f16:
         y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
-    with bn1 + ReLU applied inside conv2's input staging (am_conv_gemm_prebn): relu(bn1(.)) is never written or re-read --
-    one 4-bytes-per-element HBM pass less per block.  Both BatchNorms use batch statistics and update their running
-    statistics exactly as the unfused sequence.  Returns None when the case is not covered (caller runs the unfused blocks)."""
+    with bn1 + ReLU applied inside conv2's input staging (am_conv_gemm_prebn: the weights-in-registers kernel for C = 64, the
+    halo-staged kernel for C = 128): relu(bn1(.)) is never written or re-read -- one 4-bytes-per-element HBM pass less per block.
+    Both BatchNorms use batch statistics and update their running statistics exactly as the unfused sequence.  Returns None
+    when the case is not covered (caller runs the unfused blocks)."""
     import ctypes
     if not (FUSE_BLOCK_BN and x.dtype == torch.float16 and bn1.training and bn2.training):
         return None
     if any(t.requires_grad for t in (conv1_w, conv2_w, bn1.weight, bn1.bias, bn2.weight, bn2.bias)):
         return None
     B, H, W, C = x.shape
-    if C != 64 or tuple(conv1_w.shape) != (64, 64, 3, 3) or tuple(conv2_w.shape) != (64, 64, 3, 3):
+    if C not in (64, 128) or tuple(conv1_w.shape) != (C, C, 3, 3) or tuple(conv2_w.shape) != (C, C, 3, 3):
         return None
     L, dev = _L(), x.device
-    s = ConvSpec(64, 64, 3, 1, 1)
-    g = fwd_geom(s, B, H, W, 64, 64, 2)
+    s = ConvSpec(C, C, 3, 1, 1)
+    g = fwd_geom(s, B, H, W, C, C, 2)
     P = B * H * W
-    flops = 2.0 * P * 64 * 9 * 64
-
-    def finalize(bn, stats):
-        scale = torch.empty(64, dtype=torch.float32, device=dev)
-        shift = torch.empty_like(scale)
-        momentum = bn.momentum if bn.momentum is not None else 0.1
-        upd = bn.track_running_stats and bn.running_mean is not None
-        L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
-                         ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum), float(bn.eps), 1,
-                         ptr(scale), ptr(shift), None, None, 64, stream())
-        if upd:
-            _runtime().bump_stats_epoch()
-        if upd and bn.num_batches_tracked is not None:
-            PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
-        return scale, shift
-
+    flops = 2.0 * P * C * 9 * C
     raw1 = torch.empty_like(x)
-    stats1 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
-    conv_gemm(g, x, cache1.get_fwd(conv1_w, s, x.dtype), None, False, raw1, stats1, k_real=576)
-    sc1, sh1 = finalize(bn1, stats1)
+    stats1 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, dev)
+    conv_gemm(g, x, cache1.get_fwd(conv1_w, s, x.dtype), None, False, raw1, stats1, k_real=9 * C)
+    sc1, sh1 = _bn_finalize_nograd(bn1, stats1, P, C)
     raw2 = torch.empty_like(x)
-    stats2 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
+    stats2 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, dev)
     w2 = cache2.get_fwd(conv2_w, s, x.dtype)
     try:
         _timed("conv_gemm", flops, lambda: L.am_conv_gemm_prebn(ctypes.byref(g), AM_F16, ptr(raw1), ptr(sc1), ptr(sh1), ptr(w2), ptr(raw2),
@@ -744,11 +731,11 @@ def fused_basic_block_c64(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, 
         if "UNSUPPORTED" not in str(e):
             raise
         y1 = torch.empty_like(x)  # small problem: apply bn1 the ordinary way
-        L.am_bn_apply(AM_F16, ptr(raw1), 64, ptr(sc1), ptr(sh1), None, 0, 1, ptr(y1), 64, P, 64, stream())
-        conv_gemm(g, y1, w2, None, False, raw2, stats2, k_real=576)
-    sc2, sh2 = finalize(bn2, stats2)
+        L.am_bn_apply(AM_F16, ptr(raw1), C, ptr(sc1), ptr(sh1), None, 0, 1, ptr(y1), C, P, C, stream())
+        conv_gemm(g, y1, w2, None, False, raw2, stats2, k_real=9 * C)
+    sc2, sh2 = _bn_finalize_nograd(bn2, stats2, P, C)
     y = torch.empty_like(x)
-    L.am_bn_apply(AM_F16, ptr(raw2), 64, ptr(sc2), ptr(sh2), ptr(x), 64, 1, ptr(y), 64, P, 64, stream())
+    L.am_bn_apply(AM_F16, ptr(raw2), C, ptr(sc2), ptr(sh2), ptr(x), C, 1, ptr(y), C, P, C, stream())
     return y
 
 
@@ -798,9 +785,27 @@ def fused_basic_block_down(x, blk):
     if ld != C:
         return None
     sc1, sh1 = _bn_finalize_nograd(blk.bn1, st1, P, C)
-    y1 = torch.empty_like(raw1)
-    L.am_bn_apply(code, ptr(raw1), ld, ptr(sc1), ptr(sh1), None, 0, 1, ptr(y1), ld, P, C, stream())
-    raw2, st2, _ = _conv_stats_nograd(y1, blk.conv2.weight, blk.conv2.spec, blk.conv2._packed)
+    raw2 = st2 = None
+    s2 = blk.conv2.spec
+    if x.dtype == torch.float16 and s2.k == 3 and s2.stride == 1 and s2.pad == 1:
+        # conv2 on relu(bn1(raw1)) formed in its input staging (am_conv_gemm_prebn): the normalised map is never written
+        import ctypes
+        Bn, OH, OW, _ = raw1.shape
+        g2 = fwd_geom(s2, Bn, OH, OW, ld, ld, 2)
+        raw2 = torch.empty_like(raw1)
+        st2 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, x.device)
+        try:
+            _timed("conv_gemm", 2.0 * P * s2.cin * 9 * C, lambda: L.am_conv_gemm_prebn(
+                ctypes.byref(g2), AM_F16, ptr(raw1), ptr(sc1), ptr(sh1), ptr(blk.conv2._packed.get_fwd(blk.conv2.weight, s2, x.dtype)),
+                ptr(raw2), ptr(st2), stream()))
+        except RuntimeError as e:
+            if "UNSUPPORTED" not in str(e):
+                raise
+            raw2 = None
+    if raw2 is None:
+        y1 = torch.empty_like(raw1)
+        L.am_bn_apply(code, ptr(raw1), ld, ptr(sc1), ptr(sh1), None, 0, 1, ptr(y1), ld, P, C, stream())
+        raw2, st2, _ = _conv_stats_nograd(y1, blk.conv2.weight, blk.conv2.spec, blk.conv2._packed)
     sc2, sh2 = _bn_finalize_nograd(blk.bn2, st2, P, C)
     sc_d, sh_d = _bn_finalize_nograd(blk.downsample[1], st_d, P, C)
     y = torch.empty_like(raw2)

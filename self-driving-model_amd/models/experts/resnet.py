@@ -33,10 +33,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):  # x: NHWC
-        if self.downsample is None and self.conv1.in_channels == 64 and not torch.is_grad_enabled() or (
-                self.downsample is None and self.conv1.in_channels == 64 and not self.conv1.weight.requires_grad):
-            y = hconv.fused_basic_block_c64(x, self.conv1.weight, self.bn1, self.conv1._packed, self.conv2.weight, self.bn2,
-                                            self.conv2._packed)  # frozen layer1 block: bn1 + ReLU live inside conv2's input staging
+        if self.downsample is None and self.conv1.in_channels in (64, 128) and (not torch.is_grad_enabled() or not self.conv1.weight.requires_grad):
+            y = hconv.fused_basic_block_identity(x, self.conv1.weight, self.bn1, self.conv1._packed, self.conv2.weight, self.bn2,
+                                                 self.conv2._packed)  # frozen layer1 / layer2 block: bn1 + ReLU live inside conv2's input staging
             if y is not None:
                 return y
         if self.downsample is not None and not self.conv1.weight.requires_grad:

@@ -888,24 +888,29 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
 
 
-def test_frozen_basic_block_fused_bn_matches_unfused():
-    """Frozen ResNet layer1 block in train-mode BN, f16: bn1 + ReLU applied inside conv2's input staging (am_conv_gemm_prebn)
-    vs the unfused conv -> bn_apply -> conv sequence -- same output (f16 rounding of identical fp32 arithmetic; statistics
-    accumulate in a different order) and the same running-statistics updates, at a size with ragged edge tiles."""
+@pytest.mark.parametrize("C,shape,kernel", [(64, (2, 181, 190), "conv3x3_c64n64_duo_k"), (128, (6, 91, 150), "conv_halo_k")])
+def test_frozen_basic_block_fused_bn_matches_unfused(C, shape, kernel):
+    """Frozen ResNet layer1 / layer2 identity block in train-mode BN, f16: bn1 + ReLU applied inside conv2's input staging
+    (am_conv_gemm_prebn: weights-in-registers kernel for 64 channels, halo-staged kernel for 128) vs the unfused conv -> bn_apply
+    -> conv sequence -- same output (f16 rounding of identical fp32 arithmetic; statistics accumulate in a different order) and
+    the same running-statistics updates, at sizes with ragged edge tiles."""
+    from conftest import launched_kernel
     from self_driving_model_amd import runtime
     from self_driving_model_amd.hip import conv as hc
     from self_driving_model_amd.models.experts.resnet import BasicBlock
     dev = _dev()
-    x = (seeded_tensor((2, 181, 190, 64), 5) * 0.7).to(dev).half()  # >= 64 k pixels: the weights-in-registers kernel
+    x = (seeded_tensor((shape[0], shape[1], shape[2], C), 5) * 0.7).to(dev).half()  # large enough for the patch kernels
     outs = {}
     for fused in (False, True):
-        blk = seed_module_(BasicBlock(64, 64, 1), 17).to(dev).train()
+        blk = seed_module_(BasicBlock(C, C, 1), 17).to(dev).train()
         for p_ in blk.parameters():
             p_.requires_grad = False
         hc.FUSE_BLOCK_BN = fused
         with runtime.precision(torch.float16, 1.0):
             runtime.begin_step(dev)
             y = blk(x)
+            if fused:
+                launched_kernel(kernel, what=f"conv2 of the fused {C}-channel block")  # the block's last conv launch
             hc.flush_bn_counters()
         outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
     hc.FUSE_BLOCK_BN = True
@@ -913,6 +918,34 @@ def test_frozen_basic_block_fused_bn_matches_unfused():
     for k, v in outs[False][1].items():
         close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
     assert int(outs[True][1]["bn1.num_batches_tracked"]) == 1 and int(outs[True][1]["bn2.num_batches_tracked"]) == 1
+
+
+def test_frozen_strided_block_conv2_takes_bn1_in_its_input_staging():
+    """Frozen strided BasicBlock (64 -> 128, layer2.0) at a size the halo-staged kernel covers: conv2 reads relu(bn1(conv1)) through
+    am_conv_gemm_prebn (no normalised map), the shortcut's BatchNorm rides in the final pass; against the unfused sequence."""
+    from conftest import launched_kernel
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.models.experts.resnet import BasicBlock
+    dev = _dev()
+    x = (seeded_tensor((5, 180, 320, 64), 8) * 0.7).to(dev).half()
+    outs = {}
+    for fused in (False, True):
+        blk = seed_module_(BasicBlock(64, 128, 2), 23).to(dev).train()
+        for p_ in blk.parameters():
+            p_.requires_grad = False
+        hc.FUSE_BLOCK_BN = fused
+        with runtime.precision(torch.float16, 1.0):
+            runtime.begin_step(dev)
+            y = blk(x)
+            if fused:
+                launched_kernel("conv_halo_k", what="conv2 of the fused strided block")
+            hc.flush_bn_counters()
+        outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
+    hc.FUSE_BLOCK_BN = True
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    for k, v in outs[False][1].items():
+        close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
