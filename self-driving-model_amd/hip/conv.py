@@ -409,6 +409,7 @@ def flush_bn_counters():
     if PENDING_BN_COUNTERS:
         torch._foreach_add_(list(PENDING_BN_COUNTERS), 1)
         PENDING_BN_COUNTERS.clear()
+    _RES_GRAD_STASH.clear()  # (end of a forward: nothing of an earlier, interrupted backward may leak into this step's)
 
 
 class _Cfg:
@@ -418,6 +419,10 @@ class _Cfg:
         self.spec, self.cache, self.bn, self.relu, self.loss_scale = spec, cache, bn, relu, loss_scale
         self.orig_hw = orig_hw  # original image size when the input is the space-to-depth image (first layers)
         self.no_grad = False    # set per call by conv_bn_act(): nothing will ask this call for a gradient
+        # residual-gradient hand-off inside a BasicBlock (models/experts/resnet.py): the block end (`give`) leaves the gradient of
+        # its identity branch for the block's conv1 (`take`), whose input-gradient kernel adds it in its epilogue
+        self.give_res_grad = False
+        self.take_res_grad = False
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -528,6 +533,8 @@ class ConvBnAct(torch.autograd.Function):
             ctx.use_batch = use_batch
         ctx.cfg, ctx.geom = cfg, g
         ctx.has_res = residual is not None
+        ctx.give_key = (residual.data_ptr(), tuple(residual.shape)) if (cfg.give_res_grad and residual is not None) else None
+        ctx.take_key = (x.data_ptr(), tuple(x.shape)) if cfg.take_res_grad else None
         ctx.bn_params = (gamma, beta)
         ctx.w_param = w  # the Parameter object itself (direct-mode weight gradients go into its .grad)
         ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if (cfg.relu or bn is None) else None, mean, rstd)
@@ -592,6 +599,9 @@ class ConvBnAct(torch.autograd.Function):
             L.am_bn_bwd_apply(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), int(cfg.relu),
                               ptr(dz), ldo, ptr(dres_t), ldo, P, cout, stream())
             dres = dres_t
+            if dres is not None and ctx.give_key is not None and MERGE_RESIDUAL_GRAD:
+                _RES_GRAD_STASH[ctx.give_key] = dres  # conv1 of this block adds it to its input gradient (same tensor: the block input)
+                dres = None
             if b is not None and ctx.needs_input_grad[2]:
                 # conv bias feeding a train-mode BN has an exactly zero gradient; in eval mode it is colsum(dz)
                 db = torch.zeros_like(b)
@@ -619,9 +629,31 @@ class ConvBnAct(torch.autograd.Function):
                         raise
                     g2 = None
             if g2 is None:
-                for idx, (gd, taps) in enumerate(dgrad_plans(s, B, IH, IW, ldi, ldo, es)):
+                plans = dgrad_plans(s, B, IH, IW, ldi, ldo, es)
+                pending = _RES_GRAD_STASH.pop(ctx.take_key, None) if ctx.take_key is not None else None
+                for idx, (gd, taps) in enumerate(plans):
                     wd = cfg.cache.get_dgrad(w, s, dtype, idx, taps, ldo)
+                    if pending is not None and len(plans) == 1 and pending.shape == dx.shape and pending.dtype == dx.dtype:
+                        # dX = dgrad(dz) + (gradient of the block's identity branch) in the kernel's epilogue: no accumulate pass
+                        import ctypes
+                        try:
+                            _timed("conv_dgrad", 2.0 * gd.B * gd.MH * gd.MW * len(taps) * s.cout * gd.N,
+                                   lambda: L.am_conv_gemm_res(ctypes.byref(gd), code, ptr(dz), ptr(wd), None, ptr(pending), 0, ptr(dx), stream()))
+                            pending = None
+                            RES_GRAD_COUNTS["fused"] += 1
+                            continue
+                        except RuntimeError as e:
+                            if "UNSUPPORTED" not in str(e):
+                                raise
                     conv_gemm(gd, dz, wd, None, False, dx, None, k_real=len(taps) * s.cout, kind="conv_dgrad")
+                if pending is not None:
+                    dx.add_(pending)
+                    RES_GRAD_COUNTS["added"] += 1
+            elif ctx.take_key is not None and ctx.take_key in _RES_GRAD_STASH:
+                dx.add_(_RES_GRAD_STASH.pop(ctx.take_key))
+                RES_GRAD_COUNTS["added"] += 1
+        elif ctx.take_key is not None:
+            _RES_GRAD_STASH.pop(ctx.take_key, None)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad_oihw(g, x, dz, inv, ctx.w_param, s) if USE_WGRAD_WORKSPACE else NotImplemented
             if dw is NotImplemented:  # no slab form for this geometry: atomics into a packed staging tensor, then the re-layout
@@ -630,6 +662,11 @@ class ConvBnAct(torch.autograd.Function):
                 conv_wgrad(g, x, dz, inv, dwp, k_real=s.cin * s.k * s.k)
                 dw = unpack_wgrad(dwp, s, dtype)
         return dx, dw, db, dgamma, dbeta, dres, None, None
+
+
+MERGE_RESIDUAL_GRAD = True  # tests flip this to compare with autograd's own accumulation of the two gradients of a block input
+_RES_GRAD_STASH = {}        # (data_ptr, shape) of a block input -> gradient of the block's identity branch, until conv1's backward
+RES_GRAD_COUNTS = {"fused": 0, "added": 0}  # hand-offs taken by a conv epilogue / by an in-place add (tests)
 
 
 def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):

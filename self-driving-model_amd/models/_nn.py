@@ -33,9 +33,10 @@ class BatchNorm2d(nn.BatchNorm2d):
 
 
 def conv_bn_act(x: torch.Tensor, conv: Conv2d, bn: Optional[BatchNorm2d], relu: bool,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(BN(conv(x)) + residual) on NHWC activations; BN mode follows bn.training."""
+                residual: Optional[torch.Tensor] = None, give_residual_grad: bool = False, take_residual_grad: bool = False) -> torch.Tensor:
+    """act(BN(conv(x)) + residual) on NHWC activations; BN mode follows bn.training.  give / take_residual_grad: see hconv._Cfg."""
     cfg = hconv._Cfg(conv.spec, conv._packed, bn, relu, runtime.loss_scale())
+    cfg.give_res_grad, cfg.take_res_grad = give_residual_grad, take_residual_grad
     training = bn.training if bn is not None else False
     return hconv.conv_bn_act(x, conv.weight, conv.bias, bn, relu, residual, cfg, training)
 

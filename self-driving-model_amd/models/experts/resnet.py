@@ -43,8 +43,12 @@ class BasicBlock(nn.Module):
             if y is not None:
                 return y
         idn = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        y = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        return conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idn)
+        # identity shortcut: the block input gets two gradients (through conv1 and through the shortcut); the block end hands the
+        # shortcut's to conv1, whose input-gradient kernel adds it in its epilogue (torchvision BasicBlock.forward `out += identity`
+        # in backward: no separate accumulate pass over the block input)
+        merge = self.downsample is None and torch.is_grad_enabled() and x.requires_grad
+        y = conv_bn_act(x, self.conv1, self.bn1, relu=True, take_residual_grad=merge)
+        return conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idn, give_residual_grad=merge)
 
 
 class MaxPool(nn.MaxPool2d):

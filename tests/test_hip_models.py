@@ -888,6 +888,43 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("C,shape,fused_calls", [(64, (2, 181, 190), 1), (128, (6, 91, 150), 1), (256, (2, 24, 40), 0)])
+def test_basic_block_residual_gradient_handoff_matches_autograd_accumulation(C, shape, fused_calls):
+    """A trainable identity BasicBlock's input gets two gradients (through conv1, through the shortcut).  The block end hands
+    the shortcut's to conv1, whose input-gradient kernel adds it in its epilogue (am_conv_gemm_res; small problems: one in-place
+    add) instead of autograd accumulating two tensors: same input gradient (same two f16 roundings) and parameter gradients as
+    with the hand-off switched off, the fused entry is called where the shape has a kernel for it, nothing is left in the stash."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.models.experts.resnet import BasicBlock
+    dev = _dev()
+    x0 = (seeded_tensor((shape[0], shape[1], shape[2], C), 41) * 0.7).to(dev).half()
+    probe = seeded_tensor((shape[0], shape[1], shape[2], C), 42).to(dev).half()
+    outs = {}
+    for merge in (False, True):
+        blk = seed_module_(BasicBlock(C, C, 1), 43).to(dev).train()
+        x = x0.clone().requires_grad_()
+        hc.MERGE_RESIDUAL_GRAD = merge
+        try:
+            with runtime.precision(torch.float16, 64.0):
+                runtime.begin_step(dev)
+                before = dict(hc.RES_GRAD_COUNTS)
+                y = blk(x)
+                hc.flush_bn_counters()
+                (y.float() * probe.float()).sum().backward()
+                fused, added = (hc.RES_GRAD_COUNTS[k] - before[k] for k in ("fused", "added"))
+        finally:
+            hc.MERGE_RESIDUAL_GRAD = True
+        torch.cuda.synchronize()
+        assert (fused, added) == ((fused_calls, 1 - fused_calls) if merge else (0, 0)), (merge, fused, added)
+        assert not hc._RES_GRAD_STASH
+        outs[merge] = (y.detach().float(), x.grad.float(), {k: p_.grad.float().clone() for k, p_ in blk.named_parameters()})
+    assert rel_err(outs[True][0], outs[False][0]) < 1e-3
+    assert rel_err(outs[True][1], outs[False][1]) < 1e-3
+    for k, v in outs[False][2].items():
+        assert rel_err(outs[True][2][k], v) < 2e-3, k
+
+
 @pytest.mark.parametrize("C,shape,kernel", [(64, (2, 181, 190), "conv3x3_c64n64_duo_k"), (128, (6, 91, 150), "conv_halo_k")])
 def test_frozen_basic_block_fused_bn_matches_unfused(C, shape, kernel):
     """Frozen ResNet layer1 / layer2 identity block in train-mode BN, f16: bn1 + ReLU applied inside conv2's input staging
