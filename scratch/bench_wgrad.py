@@ -1,6 +1,6 @@
 """Per-layer conv weight-gradient micro-benchmark at the bench shapes (B=32, 720p)."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from self_driving_model_amd.hip import conv as hc
 B = int(os.environ.get("B", 32)); dt = torch.float16; dev = torch.device("cuda:0")

@@ -310,6 +310,54 @@ class PackedWeights:
         return self._layout(("dgrad", idx, tuple(taps), ld_dy), w, dtype, lambda p: pack_dgrad(p, taps, torch.float32, ld_dy))
 
 
+class PackGroup:
+    """Every trainable conv layer's packed operands rebuilt by ONE am_gather_cast launch per step instead of one per layer.
+    The master weights of a FusedAdamW model are views into one flat fp32 buffer, so the layers' index maps, shifted by their
+    parameter offsets, concatenate into one gather from that buffer into one packed buffer (each layer's PackedWeights.flat
+    becomes a slice of it).  refresh() goes first in a train step (eager, or as the first node of a captured step graph): it
+    rebuilds everything from the current master weights and marks the members fresh, so the forward / backward passes launch
+    no per-layer re-pack.  Layers that grow a new layout later (first backward) fall back to their own launch once and are
+    folded in at the next refresh; the buffers are never reallocated while the set of layouts is unchanged."""
+
+    def __init__(self, modules, flat_master: torch.Tensor):
+        self.flat_master = flat_master
+        lo, hi = flat_master.data_ptr(), flat_master.data_ptr() + flat_master.numel() * 4
+        self.members = []
+        for m in modules:
+            pw, w = getattr(m, "_packed", None), getattr(m, "weight", None)
+            if isinstance(pw, PackedWeights) and isinstance(w, torch.Tensor) and w.requires_grad and lo <= w.data_ptr() < hi:
+                self.members.append((pw, w))
+        self.sig = None
+        self.idx = self.buf = None
+        self.active = []
+
+    def refresh(self, dtype: torch.dtype):
+        if not self.members:
+            return
+        active = [(pw, w) for pw, w in self.members if pw.total > 0 and pw.idx_dev is not None]
+        if not active:
+            return
+        sig = (dtype,) + tuple((id(pw), pw.total, w.data_ptr()) for pw, w in active)
+        if sig != self.sig:
+            base = self.flat_master.data_ptr()
+            parts, total = [], 0
+            for pw, w in active:
+                off = (w.data_ptr() - base) // 4
+                parts.append(torch.where(pw.idx_dev >= 0, pw.idx_dev + off, pw.idx_dev))
+                total += pw.total
+            assert self.flat_master.numel() < (1 << 31)
+            self.idx = torch.cat(parts).to(torch.int32)
+            self.buf = torch.empty(total, dtype=dtype, device=self.flat_master.device)
+            self.sig, self.active = sig, active
+        _L().am_gather_cast(dt_code(dtype), ptr(self.flat_master), ptr(self.idx), ptr(self.buf), self.buf.numel(), stream())
+        epoch = _runtime().weight_epoch()
+        o = 0
+        for pw, w in self.active:
+            pw.flat = self.buf[o:o + pw.total]
+            pw.key, pw.fresh = (w._version, w.data_ptr(), dtype, epoch), True
+            o += pw.total
+
+
 # ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
@@ -664,7 +712,7 @@ class ConvBnAct(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, dres, None, None
 
 
-MERGE_RESIDUAL_GRAD = True  # tests flip this to compare with autograd's own accumulation of the two gradients of a block input
+MERGE_RESIDUAL_GRAD = os.environ.get("AUTOMOE_MERGE_RES_GRAD", "1") != "0"  # tests flip this to compare with autograd's own accumulation of the two gradients of a block input
 _RES_GRAD_STASH = {}        # (data_ptr, shape) of a block input -> gradient of the block's identity branch, until conv1's backward
 RES_GRAD_COUNTS = {"fused": 0, "added": 0}  # hand-offs taken by a conv epilogue / by an in-place add (tests)
 

@@ -11,11 +11,16 @@ from __future__ import annotations
 
 from typing import Iterable, List
 
+import os
+
 import torch
 
 from .. import runtime
 from ..hip import lib as _lib
 from ..hip.conv import ptr, require_hip, stream
+
+
+GROUP_CONV_PACKS = os.environ.get("AUTOMOE_GROUP_PACKS", "1") != "0"  # tests flip this to compare with the per-layer re-pack on first use
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -48,8 +53,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self.step_count = 0
         self.grad_divisor = 1.0  # world size when gradients arrive summed (training/ddp.py)
+        self.pack_group = None   # hip.conv.PackGroup: the conv layers' packed operands, rebuilt in one launch per step
+
+    def attach_conv_packs(self, modules):
+        """Conv layers among `modules` whose weights this optimizer owns get their packed operands (forward / input-gradient
+        layouts) rebuilt by ONE launch at the start of every step -- zero_grad() is the first call of a step -- instead of one
+        launch per layer on first use."""
+        from ..hip.conv import PackGroup
+        self.pack_group = PackGroup(modules, self.flat_p)
+        return self.pack_group
 
     def zero_grad(self, set_to_none: bool = False):
+        if self.pack_group is not None and GROUP_CONV_PACKS:
+            from .. import runtime
+            self.pack_group.refresh(runtime.compute_dtype())
         self.flat_g.zero_()
         for p, o in zip(self._params, self._offsets):  # autograd may have replaced a .grad view; restore it
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:

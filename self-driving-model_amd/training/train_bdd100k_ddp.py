@@ -82,6 +82,7 @@ class BDDTrainer:
         self.core.to(device)
         self.train_loader, self.val_loader = train_loader, val_loader
         self.optimizer = FusedAdamW(self.core.parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"], max_norm=1.0)
+        self.optimizer.attach_conv_packs(self.core.modules())
         self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
                                          broadcast_from=self.optimizer.flat_p)
         self.optimizer.grad_divisor = float(self.reducer.world)

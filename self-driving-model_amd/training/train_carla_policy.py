@@ -47,6 +47,7 @@ class PolicyTrainStep:
         self.model = model
         self.core = model.module if hasattr(model, "module") else model
         self.optimizer = FusedAdamW(self.core.parameters(), lr=lr, weight_decay=weight_decay, max_norm=1.0)
+        self.optimizer.attach_conv_packs(self.core.modules())
         self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
                                          broadcast_from=self.optimizer.flat_p)
         self.optimizer.grad_divisor = float(self.reducer.world)

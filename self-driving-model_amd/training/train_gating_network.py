@@ -105,6 +105,7 @@ class GatingTrainStep:
         params = [p for p in self.core.parameters() if p.requires_grad]
         self.optimizer = FusedAdamW(params, lr=config.get("learning_rate", 1e-4), weight_decay=config.get("weight_decay", 1e-4),
                                     max_norm=1.0)
+        self.optimizer.attach_conv_packs(self.core.modules())
         self.reducer = GradBucketReducer(self.optimizer._params, self.optimizer._offsets, self.optimizer.flat_g,
                                          bucket_bytes=None if bucket_mb is None else bucket_mb << 20,
                                          broadcast_from=self.optimizer.flat_p)  # None: AUTOMOE_BUCKET_MB or 25 MB

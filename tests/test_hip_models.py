@@ -888,6 +888,46 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_conv_packs_rebuilt_by_one_launch_per_step(use_graph):
+    """FusedAdamW.attach_conv_packs: every trainable conv layer's packed operands (forward + input-gradient layouts) come from
+    ONE am_gather_cast launch at the start of a step (first node of the captured step graph) instead of one launch per layer on
+    first use; same training trajectory as the per-layer re-pack, and the eager steps after the first make exactly one call."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import lib
+    from self_driving_model_amd.models.experts import BDDDrivableExpert
+    from self_driving_model_amd.training import optim, synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = _dev()
+    res = {}
+    for grouped in (False, True):
+        optim.GROUP_CONV_PACKS = grouped
+        lib.CALL_COUNTS = {}
+        try:
+            with runtime.precision(torch.float16):
+                torch.manual_seed(31)
+                m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
+                b = synthetic.bdd_drivable_batch(2, 96, 160, 3, dev, seed=6)
+                loader = synthetic.SyntheticLoader(b, 4)
+                tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t",
+                                                                      "use_graph": use_graph})
+                losses, calls = [], []
+                for _ in range(5):
+                    c0 = lib.CALL_COUNTS.get("am_gather_cast", 0)
+                    losses.append(float(tr.train_step(b)))
+                    calls.append(lib.CALL_COUNTS.get("am_gather_cast", 0) - c0)
+        finally:
+            optim.GROUP_CONV_PACKS = True
+            lib.CALL_COUNTS = None
+        res[grouped] = (losses, calls)
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-3, atol=1e-4)
+    if not use_graph:
+        assert res[True][1][2:] == [1, 1, 1], res[True][1]     # (step 0 builds the layouts layer by layer, step 1 folds them in)
+        assert min(res[False][1][1:]) >= 20, res[False][1]     # per-layer: one launch for each of the 23 conv layers
+    else:
+        assert res[True][1][-1] == 0 and res[False][1][-1] == 0  # replays launch from the graph
+
+
 @pytest.mark.parametrize("C,shape,fused_calls", [(64, (2, 181, 190), 1), (128, (6, 91, 150), 1), (256, (2, 24, 40), 0)])
 def test_basic_block_residual_gradient_handoff_matches_autograd_accumulation(C, shape, fused_calls):
     """A trainable identity BasicBlock's input gets two gradients (through conv1, through the shortcut).  The block end hands
