@@ -181,6 +181,12 @@ int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x, const void
 int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* yout, const void* raw,
                      const float* mean, const float* rstd, const float* coef, int relu, float scale, float* dw,
                      am_stream_t stream);
+/* am_conv_wgrad_bn for BatchNorm + ReLU layers WITHOUT a residual (every first layer): the ReLU mask is the sign of the layer's own
+ * normalised output raw * bn_scale[n] + bn_shift[n] (scale / shift as am_bn_finalize wrote them in forward, am_bn_apply's fp32
+ * arithmetic), recomputed from the conv output that is read anyway -- the activation tensor is not read. */
+int am_conv_wgrad_bn_sign(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* raw, const float* mean,
+                          const float* rstd, const float* coef, const float* bn_scale, const float* bn_shift, float scale,
+                          float* dw, am_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -216,6 +222,16 @@ int am_bn_bwd_finalize(const double* sums, int nrep, double count, const float* 
 int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
                     const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
                     void* dz_out, int lddz, long long P, int C, am_stream_t stream);
+/* am_bn_bwd_reduce / am_bn_bwd_apply for BatchNorm + ReLU layers WITHOUT a residual (bn1 of a BasicBlock, stems): the ReLU mask
+ * (y > 0) is the sign of x * scale[c] + shift[c] -- the layer's own normalised output, scale / shift as am_bn_finalize wrote them in
+ * forward -- recomputed from the conv output `x` both passes read anyway, so the activation tensor is not read: 2 instead of 3
+ * tensor reads in the reduce pass, 2 + 1 write instead of 3 + 1 in the apply pass.  (A positive value below half the smallest
+ * f16 subnormal was stored as 0 by am_bn_apply and masked by the *_bwd_* entries above; here it passes: fp32 autograd's rule.) */
+int am_bn_bwd_reduce_sign(int dtype, const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                          const float* scale, const float* shift, double* sums, long long P, int C, am_stream_t stream);
+int am_bn_bwd_apply_sign(int dtype, const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                         const float* coef, const float* scale, const float* shift, void* dx, int lddx, long long P, int C,
+                         am_stream_t stream);
 int am_bias_relu_bwd(int dtype, const void* dy, int lddy, const void* yout, int ldyo, int relu, void* dz_out,
                      int lddz, float* dbias, float gscale, long long P, int C, int Cvalid, am_stream_t stream);
 

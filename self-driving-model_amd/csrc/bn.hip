@@ -62,15 +62,18 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;  // chunks per pixel row
   const long long total = P * cpr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / cpr;
-    const int c0 = (int)(i - pix * cpr) * E;
-    Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
-    Vec16<T> rv;
-    if (res) rv = *reinterpret_cast<const Vec16<T>*>(res + pix * ldr + c0);
-    // per-channel constants of this chunk as 16-byte loads (c0 is a multiple of E): left to itself hipcc issues them one dword
-    // at a time with a wait in front of each use
-    float sc[E], sh[E], rs[E], rh[E];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  // The launch has a multiple of 256 threads: when cpr divides 256 (every power-of-two channel count of the trunks) a thread
+  // meets the SAME channel chunk in every iteration, so its per-channel constants are loaded once, the pixel advances by a
+  // constant and the loop body is the data loads, the arithmetic and the store (per iteration the constants used to be four
+  // 16-byte loads next to two or three of data).  Other channel counts re-derive chunk and constants per iteration.
+  const bool fixed = (256 % cpr) == 0;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long pix = i / cpr;
+  int c0 = (int)(i - pix * cpr) * E;
+  const long long pix_step = fixed ? stride / cpr : 0;
+  float sc[E], sh[E], rs[E], rh[E];
+  auto load_consts = [&]() {
 #pragma unroll
     for (int e = 0; e < E; e += 4) {
       *reinterpret_cast<f32x4*>(sc + e) = *reinterpret_cast<const f32x4*>(scale + c0 + e);
@@ -80,6 +83,17 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
         *reinterpret_cast<f32x4*>(rh + e) = *reinterpret_cast<const f32x4*>(rshift + c0 + e);
       }
     }
+  };
+  if (i < total) load_consts();
+  for (; i < total; i += stride) {
+    if (!fixed) {
+      pix = i / cpr;
+      c0 = (int)(i - pix * cpr) * E;
+      load_consts();
+    }
+    Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
+    Vec16<T> rv;
+    if (res) rv = *reinterpret_cast<const Vec16<T>*>(res + pix * ldr + c0);
     Vec16<T> out;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
       out.v[e] = am_from_f32<T>(v);
     }
     *reinterpret_cast<Vec16<T>*>(y + pix * ldy + c0) = out;
+    pix += pix_step;
   }
 }
 
@@ -103,7 +118,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* __restrict__ dy, int lddy, const T* __restrict__ yout, int ldyo,
                                                        const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int relu, double* __restrict__ sums,
-                                                       long long P, int C) {
+                                                       long long P, int C, const float* __restrict__ sg_scale,
+                                                       const float* __restrict__ sg_shift) {
+  // sg_scale / sg_shift (the *_sign entries): the layer has no residual, so its ReLU mask is the sign of its own normalised
+  // output x * scale + shift (am_bn_apply's fp32 arithmetic) -- recomputed from the conv output that is read anyway instead of
+  // reading the activation tensor
   constexpr int E = 16 / (int)sizeof(T);
   extern __shared__ float red[];  // [256][2*E]
   const int cpr = C / E;
@@ -116,20 +135,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* __restrict__ dy,
   for (int e = 0; e < E; ++e) s[e] = q[e] = 0.f;
   if (cpr <= 256 && rloc < rpp) {
     const int c0 = chunk * E;
-    float mu[E], rs[E];
+    float mu[E], rs[E], sc[E], sh[E];
+    const bool sign = sg_scale != nullptr;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; }
+    for (int e = 0; e < E; ++e) {
+      mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e];
+      sc[e] = sign ? sg_scale[c0 + e] : 0.f; sh[e] = sign ? sg_shift[c0 + e] : 0.f;
+    }
+    const bool mask_y = relu && !sign;
     for (long long pix = (long long)blockIdx.x * rpp + rloc; pix < P; pix += (long long)gridDim.x * rpp) {
       Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(dy + pix * lddy + c0);
       Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
       Vec16<T> yo;
-      if (relu) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
+      if (mask_y) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         float dz = am_to_f32(g.v[e]);
-        if (relu && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+        const float xf = am_to_f32(xv.v[e]);
+        if (mask_y && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+        if (sign && !(xf * sc[e] + sh[e] > 0.f)) dz = 0.f;
         s[e] += dz;
-        q[e] += dz * (am_to_f32(xv.v[e]) - mu[e]) * rs[e];
+        q[e] += dz * (xf - mu[e]) * rs[e];
       }
     }
   }
@@ -173,29 +199,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* __restrict__ dy, 
                                                       const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ coef, int relu,
                                                       T* __restrict__ dx, int lddx, T* __restrict__ dz_out, int lddz,
-                                                      long long P, int C) {
+                                                      long long P, int C, const float* __restrict__ sg_scale,
+                                                      const float* __restrict__ sg_shift) {
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;
   const long long total = P * cpr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / cpr;
-    const int c0 = (int)(i - pix * cpr) * E;
+  const bool sign = sg_scale != nullptr, mask_y = relu && !sign;  // (see bn_bwd_reduce_k)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const bool fixed = (256 % cpr) == 0;  // the thread's channel chunk is loop-invariant: constants in registers (see bn_apply_k)
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long pix = i / cpr;
+  int c0 = (int)(i - pix * cpr) * E;
+  const long long pix_step = fixed ? stride / cpr : 0;
+  float mu[E], rs[E], k0[E], k1[E], k2[E], ssc[E], ssh[E];
+  auto load_consts = [&]() {
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      *reinterpret_cast<f32x4*>(mu + e) = *reinterpret_cast<const f32x4*>(mean + c0 + e);
+      *reinterpret_cast<f32x4*>(rs + e) = *reinterpret_cast<const f32x4*>(rstd + c0 + e);
+      *reinterpret_cast<f32x4*>(k0 + e) = *reinterpret_cast<const f32x4*>(coef + c0 + e);
+      *reinterpret_cast<f32x4*>(k1 + e) = *reinterpret_cast<const f32x4*>(coef + C + c0 + e);
+      *reinterpret_cast<f32x4*>(k2 + e) = *reinterpret_cast<const f32x4*>(coef + 2 * C + c0 + e);
+      if (sign) {
+        *reinterpret_cast<f32x4*>(ssc + e) = *reinterpret_cast<const f32x4*>(sg_scale + c0 + e);
+        *reinterpret_cast<f32x4*>(ssh + e) = *reinterpret_cast<const f32x4*>(sg_shift + c0 + e);
+      }
+    }
+  };
+  if (i < total) load_consts();
+  for (; i < total; i += stride) {
+    if (!fixed) {
+      pix = i / cpr;
+      c0 = (int)(i - pix * cpr) * E;
+      load_consts();
+    }
     Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(dy + pix * lddy + c0);
     Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + pix * ldx + c0);
     Vec16<T> yo;
-    if (relu) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
+    if (mask_y) yo = *reinterpret_cast<const Vec16<T>*>(yout + pix * ldyo + c0);
     Vec16<T> o, z;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int c = c0 + e;
       float dz = am_to_f32(g.v[e]);
-      if (relu && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
-      const float xhat = (am_to_f32(xv.v[e]) - mean[c]) * rstd[c];
-      o.v[e] = am_from_f32<T>(coef[c] * (dz - coef[C + c] - xhat * coef[2 * C + c]));
+      const float xf = am_to_f32(xv.v[e]);
+      if (mask_y && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
+      if (sign && !(xf * ssc[e] + ssh[e] > 0.f)) dz = 0.f;
+      const float xhat = (xf - mu[e]) * rs[e];
+      o.v[e] = am_from_f32<T>(k0[e] * (dz - k1[e] - xhat * k2[e]));
       z.v[e] = am_from_f32<T>(dz);
     }
     *reinterpret_cast<Vec16<T>*>(dx + pix * lddx + c0) = o;
     if (dz_out) *reinterpret_cast<Vec16<T>*>(dz_out + pix * lddz + c0) = z;
+    pix += pix_step;
   }
 }
 
@@ -301,9 +356,9 @@ extern "C" int am_bn_apply2(int dtype, const void* x, int ldx, const float* scal
   return AM_OK;
 }
 
-extern "C" int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
-                                const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
-                                am_stream_t stream) {
+static int bn_bwd_reduce_impl(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                              const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
+                              const float* sg_scale, const float* sg_shift, am_stream_t stream) {
   const int es = dtype == AM_F16 ? 2 : 4;
   if ((dtype != AM_F16 && dtype != AM_F32) || !dy || !x || !mean || !rstd || !sums || (relu && !yout) || C <= 0) return AM_ERR_ARG;
   if (AM_EW_CHECK(C, ldx, es) || (lddy * es) % 16 != 0 || (relu && (ldyo * es) % 16 != 0)) return AM_ERR_ARG;
@@ -317,11 +372,23 @@ extern "C" int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void*
   const size_t lds = 256 * 2 * E * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16)
-    hipLaunchKernelGGL(bn_bwd_reduce_k<half_t>, dim3(grid), dim3(256), lds, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, relu, sums, P, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_k<half_t>, dim3(grid), dim3(256), lds, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, relu, sums, P, C, sg_scale, sg_shift);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(grid), dim3(256), lds, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, relu, sums, P, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(grid), dim3(256), lds, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, relu, sums, P, C, sg_scale, sg_shift);
   AM_CHECK_LAUNCH();
   return AM_OK;
+}
+
+extern "C" int am_bn_bwd_reduce(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                                const float* mean, const float* rstd, int relu, double* sums, long long P, int C,
+                                am_stream_t stream) {
+  return bn_bwd_reduce_impl(dtype, dy, lddy, yout, ldyo, x, ldx, mean, rstd, relu, sums, P, C, nullptr, nullptr, stream);
+}
+
+extern "C" int am_bn_bwd_reduce_sign(int dtype, const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                                     const float* scale, const float* shift, double* sums, long long P, int C, am_stream_t stream) {
+  if (!scale || !shift) return AM_ERR_ARG;
+  return bn_bwd_reduce_impl(dtype, dy, lddy, nullptr, 0, x, ldx, mean, rstd, 0, sums, P, C, scale, shift, stream);
 }
 
 extern "C" int am_bn_bwd_finalize(const double* sums, int nrep, double count, const float* gamma, const float* rstd,
@@ -332,9 +399,10 @@ extern "C" int am_bn_bwd_finalize(const double* sums, int nrep, double count, co
   return AM_OK;
 }
 
-extern "C" int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
-                               const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
-                               void* dz_out, int lddz, long long P, int C, am_stream_t stream) {
+static int bn_bwd_apply_impl(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                             const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
+                             void* dz_out, int lddz, long long P, int C, const float* sg_scale, const float* sg_shift,
+                             am_stream_t stream) {
   const int es = dtype == AM_F16 ? 2 : 4;
   if ((dtype != AM_F16 && dtype != AM_F32) || !dy || !x || !mean || !rstd || !coef || !dx || (relu && !yout) || C <= 0) return AM_ERR_ARG;
   if (AM_EW_CHECK(C, ldx, es) || (lddy * es) % 16 != 0 || (lddx * es) % 16 != 0 || (relu && (ldyo * es) % 16 != 0) || (dz_out && (lddz * es) % 16 != 0)) return AM_ERR_ARG;
@@ -342,11 +410,24 @@ extern "C" int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* 
   const int grid = ew_grid(P * (C * es / 16));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16)
-    hipLaunchKernelGGL(bn_bwd_apply_k<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, coef, relu, (half_t*)dx, lddx, (half_t*)dz_out, lddz, P, C);
+    hipLaunchKernelGGL(bn_bwd_apply_k<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, coef, relu, (half_t*)dx, lddx, (half_t*)dz_out, lddz, P, C, sg_scale, sg_shift);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, coef, relu, (float*)dx, lddx, (float*)dz_out, lddz, P, C);
+    hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)yout, ldyo, (const float*)x, ldx, mean, rstd, coef, relu, (float*)dx, lddx, (float*)dz_out, lddz, P, C, sg_scale, sg_shift);
   AM_CHECK_LAUNCH();
   return AM_OK;
+}
+
+extern "C" int am_bn_bwd_apply(int dtype, const void* dy, int lddy, const void* yout, int ldyo, const void* x, int ldx,
+                               const float* mean, const float* rstd, const float* coef, int relu, void* dx, int lddx,
+                               void* dz_out, int lddz, long long P, int C, am_stream_t stream) {
+  return bn_bwd_apply_impl(dtype, dy, lddy, yout, ldyo, x, ldx, mean, rstd, coef, relu, dx, lddx, dz_out, lddz, P, C, nullptr, nullptr, stream);
+}
+
+extern "C" int am_bn_bwd_apply_sign(int dtype, const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                                    const float* coef, const float* scale, const float* shift, void* dx, int lddx, long long P, int C,
+                                    am_stream_t stream) {
+  if (!scale || !shift) return AM_ERR_ARG;
+  return bn_bwd_apply_impl(dtype, dy, lddy, nullptr, 0, x, ldx, mean, rstd, coef, 0, dx, lddx, nullptr, 0, P, C, scale, shift, stream);
 }
 
 extern "C" int am_bias_relu_bwd(int dtype, const void* dy, int lddy, const void* yout, int ldyo, int relu, void* dz_out,

@@ -604,7 +604,8 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s, bool plan_only = false) {
 int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
                            bool plan_only, hipStream_t s);  // conv_wgrad_ring.hip
 int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
-                          const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s);  // conv_s2d_wgrad.hip
+                          const float* rstd, const float* coef, int relu, const float* sg_scale, const float* sg_shift, float scale, float* dw,
+                          hipStream_t s);  // conv_s2d_wgrad.hip
 int am_conv_gemm2_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, void* y, double* stats,
                       hipStream_t s);  // conv_gemm2.hip
 int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* w, const float* bias, const float* scale,
@@ -707,7 +708,7 @@ static int wgrad_dispatch(const am_conv_geom* g, int dtype, const void* x, const
   if (dtype == AM_F16) {
     if (g->pix_shift == 4) {  // first layers on the space-to-depth image: dY read once (conv_s2d_wgrad.hip); atomic form only
       if (plan_only || ws) return plan_only ? 0 : AM_ERR_UNSUPPORTED;
-      const int rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scale, dw, s);
+      const int rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, scale, dw, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
     const int rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, ws, ws_stride, plan_only, s);  // LDS-DMA ring kernel: N % 128 == 0, long contractions
@@ -816,7 +817,18 @@ extern "C" int am_conv_wgrad_bn(const am_conv_geom* g, int dtype, const void* x,
   if (!x || !dy || !raw || !mean || !rstd || !coef || !dw || (relu && !yout) || g->ntaps <= 0) return AM_ERR_ARG;
   if (dtype != AM_F16 || g->pix_shift != 4) return AM_ERR_UNSUPPORTED;
   if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
-  return am_conv_s2d_wgrad_f16(g, x, dy, yout, raw, mean, rstd, coef, relu, scale, dw, static_cast<hipStream_t>(stream));
+  return am_conv_s2d_wgrad_f16(g, x, dy, yout, raw, mean, rstd, coef, relu, nullptr, nullptr, scale, dw, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int am_conv_wgrad_bn_sign(const am_conv_geom* g, int dtype, const void* x, const void* dy, const void* raw, const float* mean,
+                                     const float* rstd, const float* coef, const float* bn_scale, const float* bn_shift, float scale,
+                                     float* dw, am_stream_t stream) {
+  int rc = check_geom(g, dtype);
+  if (rc != AM_OK) return rc;
+  if (!x || !dy || !raw || !mean || !rstd || !coef || !bn_scale || !bn_shift || !dw || g->ntaps <= 0) return AM_ERR_ARG;
+  if (dtype != AM_F16 || g->pix_shift != 4) return AM_ERR_UNSUPPORTED;
+  if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
+  return am_conv_s2d_wgrad_f16(g, x, dy, nullptr, raw, mean, rstd, coef, 1, bn_scale, bn_shift, scale, dw, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,

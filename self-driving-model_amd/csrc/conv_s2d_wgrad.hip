@@ -33,6 +33,9 @@ struct S2dWgradParams {
   const void* yout;  // BN+ReLU output (ReLU mask), NULL without ReLU
   const float* mean; const float* rstd; const float* coef;  // coef = [3][N] from am_bn_bwd_finalize
   int relu;
+  // ReLU mask recomputed as the sign of raw * sg_scale + sg_shift (the layer's own normalised output: no residual on a first
+  // layer) instead of reading yout: one tensor less per launch
+  const float* sg_scale; const float* sg_shift;
 };
 
 typedef __attribute__((address_space(3))) s4v* lds_s4v;
@@ -84,12 +87,13 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jp][r] = 0.f;
 
-  // BNF: per-channel constants in LDS ([5][64]: mean, rstd, coef0..2); a thread always handles the same 8-channel chunk
+  // BNF: per-channel constants in LDS ([7][64]: mean, rstd, coef0..2, sign scale / shift); a thread always handles the same 8-channel chunk
   float* bnc = reinterpret_cast<float*>(dYs + TH * TW * PDY);
+  const bool sign = BNF && p.sg_scale != nullptr;
   if constexpr (BNF) {
-    for (int i = tid; i < 5 * 64; i += NTH) {
+    for (int i = tid; i < 7 * 64; i += NTH) {
       const int c = min(i & 63, p.N - 1), f = i >> 6;
-      bnc[i] = f == 0 ? p.mean[c] : f == 1 ? p.rstd[c] : p.coef[(f - 2) * p.N + c];
+      bnc[i] = f == 0 ? p.mean[c] : f == 1 ? p.rstd[c] : f < 5 ? p.coef[(f - 2) * p.N + c] : !sign ? 0.f : f == 5 ? p.sg_scale[c] : p.sg_shift[c];
     }
   }
   const half_t* __restrict__ raw = static_cast<const half_t*>(p.raw);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
         v = *reinterpret_cast<const uint4*>(dy + off);
         if constexpr (BNF) {
           xr = *reinterpret_cast<const uint4*>(raw + off);
-          if (p.relu) yr = *reinterpret_cast<const uint4*>(yout + off);
+          if (p.relu && !sign) yr = *reinterpret_cast<const uint4*>(yout + off);
         }
       }
       rd[k] = v;
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
     for (int e = 0; e < 8; ++e) {
       const int c = cc * 8 + e;
       float dz = (float)gv[e];
-      if (p.relu && !((float)yv[e] > 0.f)) dz = 0.f;
+      if (p.relu && !sign && !((float)yv[e] > 0.f)) dz = 0.f;
+      if (sign && !((float)xv[e] * bnc[320 + c] + bnc[384 + c] > 0.f)) dz = 0.f;
       const float xhat = ((float)xv[e] - bnc[c]) * bnc[64 + c];
       o[e] = c < p.N ? (half_t)(bnc[128 + c] * (dz - bnc[192 + c] - xhat * bnc[256 + c])) : (half_t)0.f;
     }
@@ -221,7 +226,7 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int PATCH = ((PH * PW * PPITCH + 1023) / 1024) * 1024;
   constexpr int DYS = TH * TW * (NT == 1 ? 64 : 192);
   constexpr int RED = NT * 32 * TAPS * 64 * 4;
-  constexpr int LDS = (PATCH + DYS + 5 * 64 * 4) > RED ? (PATCH + DYS + 5 * 64 * 4) : RED;
+  constexpr int LDS = (PATCH + DYS + 7 * 64 * 4) > RED ? (PATCH + DYS + 7 * 64 * 4) : RED;
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (LDS > 64 * 1024 && !attr_done) {
@@ -240,9 +245,10 @@ int launch(const S2dWgradParams& p, hipStream_t s) {
 
 // Called by am_conv_wgrad / am_conv_wgrad_bn (conv_gemm.hip) for first-layer (space-to-depth) geometries in f16; returns
 // AM_ERR_UNSUPPORTED when the shape is not covered so the caller uses the generic kernel(s).  raw != NULL selects the fused
-// BatchNorm-backward form.
+// BatchNorm-backward form; sg_scale / sg_shift != NULL its variant that takes the ReLU mask from the sign of the normalised output.
 int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
-                          const float* rstd, const float* coef, int relu, float scale, float* dw, hipStream_t s) {
+                          const float* rstd, const float* coef, int relu, const float* sg_scale, const float* sg_shift, float scale, float* dw,
+                          hipStream_t s) {
   using namespace amw;
   if (g->pix_shift != 4 || g->krun != 64 || g->ldi != 16 || g->x_coff != 0) return AM_ERR_UNSUPPORTED;
   if (g->ntaps < 3 || g->ntaps > 4 || g->N > 64) return AM_ERR_UNSUPPORTED;
@@ -259,8 +265,9 @@ int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, 
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
   p.raw = raw; p.yout = yout; p.mean = mean; p.rstd = rstd; p.coef = coef; p.relu = relu;
+  p.sg_scale = sg_scale; p.sg_shift = sg_shift;
   if (raw != nullptr) {
-    if (!mean || !rstd || !coef || (relu && !yout)) return AM_ERR_ARG;
+    if (!mean || !rstd || !coef || (relu && !yout && !sg_scale) || (sg_scale && !sg_shift)) return AM_ERR_ARG;
     if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, true>(p, s) : launch<4, 1, true>(p, s);
     return g->ntaps == 3 ? launch<3, 2, true>(p, s) : launch<4, 2, true>(p, s);
   }

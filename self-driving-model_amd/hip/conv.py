@@ -579,6 +579,9 @@ class ConvBnAct(torch.autograd.Function):
             L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
                           residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
             ctx.use_batch = use_batch
+            # BatchNorm + ReLU without a residual: backward takes the ReLU mask from the sign of raw * scale + shift (the *_sign
+            # entries) instead of reading y -- one tensor read less in each of its passes
+            ctx.sign_ss = (scale, shift) if (SIGN_RELU_MASK and cfg.relu and residual is None) else None
         ctx.cfg, ctx.geom = cfg, g
         ctx.has_res = residual is not None
         ctx.give_key = (residual.data_ptr(), tuple(residual.shape)) if (cfg.give_res_grad and residual is not None) else None
@@ -604,8 +607,13 @@ class ConvBnAct(torch.autograd.Function):
         db = dgamma = dbeta = dres = None
         if cfg.bn is not None:
             sums = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev)
-            L.am_bn_bwd_reduce(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), int(cfg.relu), ptr(sums), P,
-                               cout, stream())
+            sign_ss = ctx.sign_ss
+            if sign_ss is not None:
+                L.am_bn_bwd_reduce_sign(code, ptr(dy), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(sign_ss[0]), ptr(sign_ss[1]), ptr(sums), P,
+                                        cout, stream())
+            else:
+                L.am_bn_bwd_reduce(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), int(cfg.relu), ptr(sums), P,
+                                   cout, stream())
             coef = torch.empty(3 * cout, dtype=torch.float32, device=dev)
             need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
             gp, bp = ctx.bn_params
@@ -630,9 +638,14 @@ class ConvBnAct(torch.autograd.Function):
                 ktot = g.ntaps * g.krun
                 dwp = torch.zeros(cout, ktot, dtype=torch.float32, device=dev)
                 try:
-                    _timed("conv_wgrad", 2.0 * P * s.cin * s.k * s.k * cout,
-                           lambda: L.am_conv_wgrad_bn(ctypes.byref(g), code, ptr(x), ptr(dy), ptr(y) if cfg.relu else None, ptr(raw), ptr(mean),
-                                                      ptr(rstd), ptr(coef), int(cfg.relu), inv, ptr(dwp), stream()))
+                    if sign_ss is not None:
+                        _timed("conv_wgrad", 2.0 * P * s.cin * s.k * s.k * cout,
+                               lambda: L.am_conv_wgrad_bn_sign(ctypes.byref(g), code, ptr(x), ptr(dy), ptr(raw), ptr(mean), ptr(rstd), ptr(coef),
+                                                               ptr(sign_ss[0]), ptr(sign_ss[1]), inv, ptr(dwp), stream()))
+                    else:
+                        _timed("conv_wgrad", 2.0 * P * s.cin * s.k * s.k * cout,
+                               lambda: L.am_conv_wgrad_bn(ctypes.byref(g), code, ptr(x), ptr(dy), ptr(y) if cfg.relu else None, ptr(raw), ptr(mean),
+                                                          ptr(rstd), ptr(coef), int(cfg.relu), inv, ptr(dwp), stream()))
                     fused_wgrad = True
                 except RuntimeError as e:
                     if "UNSUPPORTED" not in str(e):
@@ -644,8 +657,12 @@ class ConvBnAct(torch.autograd.Function):
                 return None, dw, db, dgamma, dbeta, None, None, None
             dz = torch.empty_like(dy)
             dres_t = torch.empty_like(dy) if (ctx.has_res and ctx.needs_input_grad[5]) else None
-            L.am_bn_bwd_apply(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), int(cfg.relu),
-                              ptr(dz), ldo, ptr(dres_t), ldo, P, cout, stream())
+            if sign_ss is not None:
+                L.am_bn_bwd_apply_sign(code, ptr(dy), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), ptr(sign_ss[0]), ptr(sign_ss[1]),
+                                       ptr(dz), ldo, P, cout, stream())
+            else:
+                L.am_bn_bwd_apply(code, ptr(dy), ldo, ptr(y), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(coef), int(cfg.relu),
+                                  ptr(dz), ldo, ptr(dres_t), ldo, P, cout, stream())
             dres = dres_t
             if dres is not None and ctx.give_key is not None and MERGE_RESIDUAL_GRAD:
                 _RES_GRAD_STASH[ctx.give_key] = dres  # conv1 of this block adds it to its input gradient (same tensor: the block input)
@@ -712,6 +729,7 @@ class ConvBnAct(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, dres, None, None
 
 
+SIGN_RELU_MASK = os.environ.get("AUTOMOE_SIGN_RELU_MASK", "1") != "0"  # tests flip this to compare with the mask read from the activation
 MERGE_RESIDUAL_GRAD = os.environ.get("AUTOMOE_MERGE_RES_GRAD", "1") != "0"  # tests flip this to compare with autograd's own accumulation of the two gradients of a block input
 _RES_GRAD_STASH = {}        # (data_ptr, shape) of a block input -> gradient of the block's identity branch, until conv1's backward
 RES_GRAD_COUNTS = {"fused": 0, "added": 0}  # hand-offs taken by a conv epilogue / by an in-place add (tests)

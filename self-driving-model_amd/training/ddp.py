@@ -170,6 +170,18 @@ class GradBucketReducer:
         return int(t.item())
 
 
+def _quiesce_collectives(reducer: "GradBucketReducer"):
+    """Before a capture begins: every eager collective issued so far (the mode agreement, earlier steps' buckets) has finished AND
+    has been reaped by the process group's watchdog thread, so that thread has no event left to poll while this thread captures.
+    (c10d's watchdog calls hipEventQuery on the events of outstanding work about every 100 ms; a query that lands inside
+    another thread's capture window was seen once, in a full test-suite run, to come back with a HIP error and abort the process --
+    capture_error_mode="thread_local" is meant to allow it.  Captured collectives themselves are never handed to the watchdog.)"""
+    if reducer.enabled and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.3)
+
+
 def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step"):
     """Capture one training step into a hipGraph in the best mode every rank can reach.
 
@@ -185,6 +197,7 @@ def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step
         reducer.paused = reducer.enabled and want == 1
         reducer.reset()
         got = want
+        _quiesce_collectives(reducer)
         try:
             graph, result = capture_fn(want == 2)
         except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back, loudly)

@@ -112,12 +112,14 @@ def test_conv_fwd_bwd_vs_torch(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("with_res,conv_bias", [(False, False), (True, False), (False, True)])
-def test_conv_bn_relu_train_vs_torch(dtype, with_res, conv_bias):
-    """conv -> BatchNorm2d(train) -> (+residual) -> ReLU, forward, running stats, all gradients."""
+@pytest.mark.parametrize("with_res,conv_bias,sign_mask", [(False, False, True), (False, False, False), (True, False, True), (False, True, True)])
+def test_conv_bn_relu_train_vs_torch(dtype, with_res, conv_bias, sign_mask):
+    """conv -> BatchNorm2d(train) -> (+residual) -> ReLU, forward, running stats, all gradients.  sign_mask: backward takes the
+    ReLU mask from the sign of the normalised conv output (the *_sign entries; layers without a residual) or from the activation."""
     import torch.nn as nn
     from self_driving_model_amd import runtime
     from self_driving_model_amd.hip import conv as hc
+    hc.SIGN_RELU_MASK = sign_mask
     B, cin, cout, H, W = 4, 64, 128, 9, 14
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, cin, H, W, generator=g)
@@ -168,6 +170,7 @@ def test_conv_bn_relu_train_vs_torch(dtype, with_res, conv_bias):
         assert rel_err(nchw(xd.grad, cin), xr.grad) < 4e-2
         assert rel_err(wd.grad, wr.grad) < 4e-2
         assert rel_err(bn_hip.weight.grad, bn_ref.weight.grad) < 4e-2
+    hc.SIGN_RELU_MASK = True
 
 
 def test_bn_eval_mode_vs_torch():
@@ -614,7 +617,12 @@ def test_conv_big_tile_variant_vs_torch(case):
     assert B * OH * OW >= 65536
     y = torch.zeros(B, OH, OW, cout, dtype=torch.float16, device=_dev())
     stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
-    hc.conv_gemm(hc.fwd_geom(s, B, H, W, cin, cout, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), None, False, y, stats)
+    from self_driving_model_amd.hip import lib
+    old_halo = lib.get().am_set_tuning(lib.AM_TUNE_HALO_MIN_TILES, 1 << 30)  # (the 3x3 / stride-1 N = 128 case would take conv_halo_k: its own test)
+    try:
+        hc.conv_gemm(hc.fwd_geom(s, B, H, W, cin, cout, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16), None, False, y, stats)
+    finally:
+        lib.get().am_set_tuning(lib.AM_TUNE_HALO_MIN_TILES, old_halo)
     launched_kernel("conv_ring_k<256,128>" if cout == 128 else "conv_ring16_k<256,256>", what=f"big tile {case}")
     torch.cuda.synchronize()
     close(nchw(y, cout), yr, rtol=3e-3, atol=3e-3)
@@ -675,23 +683,33 @@ def test_first_layer_weight_gradient_kernels_vs_torch(spec):
     with torch.no_grad():
         bn_ref.weight.copy_(gamma); bn_ref.bias.copy_(beta)
     (F.relu(bn_ref(F.conv2d(img.half().float(), wr, br, stride=2, padding=pad))) * probe).sum().backward()
-    # HIP
+    # HIP: the ReLU mask from the sign of the normalised conv output (am_conv_wgrad_bn_sign, am_bn_bwd_reduce_sign: the default)
+    # and from the stored activation (am_conv_wgrad_bn, am_bn_bwd_reduce)
     s = hc.ConvSpec(3, cout, k, 2, pad, first=True)
-    bn = nn.BatchNorm2d(cout)
-    with torch.no_grad():
-        bn.weight.copy_(gamma); bn.bias.copy_(beta)
-    bn.to(_dev()).train()
-    wd = w.to(_dev()).requires_grad_()
-    bd = bvec.to(_dev()).requires_grad_() if bias else None
-    with runtime.precision(torch.float16, 1.0):
-        x = hops.image_to_s2d(img.to(_dev()), torch.float16)
-        y = hc.conv_bn_act(x, wd, bd, bn, True, None, hc._Cfg(s, hc.PackedWeights(), bn, True, 1.0), True)
-        yf = hops.NhwcToNchw.apply(y, cout, 1.0)
-        (yf * probe.to(_dev())).sum().backward()
-    assert rel_err(wd.grad, wr.grad) < 2e-2, rel_err(wd.grad, wr.grad)
-    assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 1e-2 and rel_err(bn.bias.grad, bn_ref.bias.grad) < 1e-2
-    if bias:
-        assert float(bd.grad.abs().max()) == 0.0  # a bias in front of a train-mode BN has an exactly zero gradient
+    grads = {}
+    for sign in (True, False):
+        bn = nn.BatchNorm2d(cout)
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        bn.to(_dev()).train()
+        wd = w.to(_dev()).requires_grad_()
+        bd = bvec.to(_dev()).requires_grad_() if bias else None
+        hc.SIGN_RELU_MASK = sign
+        try:
+            with runtime.precision(torch.float16, 1.0):
+                x = hops.image_to_s2d(img.to(_dev()), torch.float16)
+                y = hc.conv_bn_act(x, wd, bd, bn, True, None, hc._Cfg(s, hc.PackedWeights(), bn, True, 1.0), True)
+                yf = hops.NhwcToNchw.apply(y, cout, 1.0)
+                (yf * probe.to(_dev())).sum().backward()
+        finally:
+            hc.SIGN_RELU_MASK = True
+        assert rel_err(wd.grad, wr.grad) < 2e-2, rel_err(wd.grad, wr.grad)
+        assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 1e-2 and rel_err(bn.bias.grad, bn_ref.bias.grad) < 1e-2
+        if bias:
+            assert float(bd.grad.abs().max()) == 0.0  # a bias in front of a train-mode BN has an exactly zero gradient
+        grads[sign] = (wd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    for a, b in zip(grads[True], grads[False]):
+        assert rel_err(a, b) < 1e-4  # the two masks differ only where the activation underflowed f16
     # the plain (no BatchNorm) form of the same kernel: dW from an explicit conv-output gradient vs torch.nn.grad.conv2d_weight
     with runtime.precision(torch.float16, 1.0):
         x = hops.image_to_s2d(img.to(_dev()), torch.float16)
