@@ -65,32 +65,56 @@ struct Cand {
   double v;
   int it;       // position in `remaining`
   int unas;     // column unassigned?
+  int j;        // the column at that position
 };
 
-__device__ __forceinline__ Cand better(const Cand& a, const Cand& b) {
-  // result of scanning both in position order with: take if v < lowest || (v == lowest && unassigned)
-  if (a.it < 0) return b;
-  if (b.it < 0) return a;
-  if (a.v < b.v) return a;
-  if (b.v < a.v) return b;
-  if (a.unas != b.unas) return a.unas ? a : b;
-  if (a.unas) return a.it > b.it ? a : b;  // last unassigned wins
-  return a.it < b.it ? a : b;              // first assigned stays
+// result of scanning both in position order with: take if v < lowest || (v == lowest && unassigned).  Written as one predicate
+// and four selects on scalars: with by-reference structs hipcc kept the candidates in scratch memory (80 bytes of private
+// segment), i.e. every combine of every inner step went through global memory -- 4 us per step
+__device__ __forceinline__ Cand better(Cand a, Cand b) {
+  const bool b_wins = a.it < 0 ? true
+                      : b.it < 0 ? false
+                      : b.v < a.v ? true
+                      : a.v < b.v ? false
+                      : a.unas != b.unas ? b.unas != 0
+                      : a.unas ? b.it > a.it   // last unassigned wins
+                               : b.it < a.it;  // first assigned stays
+  Cand r;
+  r.v = b_wins ? b.v : a.v;
+  r.it = b_wins ? b.it : a.it;
+  r.unas = b_wins ? b.unas : a.unas;
+  r.j = b_wins ? b.j : a.j;
+  return r;
 }
 
-__device__ __forceinline__ Cand shfl_cand(const Cand& c, int off) {
+__device__ __forceinline__ Cand shfl_cand(Cand c, int off) {
   Cand r;
   r.v = __shfl_xor(c.v, off, 64);
   r.it = __shfl_xor(c.it, off, 64);
   r.unas = __shfl_xor(c.unas, off, 64);
+  r.j = __shfl_xor(c.j, off, 64);
   return r;
+}
+
+// the four wave candidates of a step, as scalars in LDS (no aggregate copies)
+struct WaveBest {
+  double v[2][4];
+  int it[2][4], unas[2][4], j[2][4];
+};
+__device__ __forceinline__ void put_best(WaveBest& w, int par, int wid, Cand c) {
+  w.v[par][wid] = c.v; w.it[par][wid] = c.it; w.unas[par][wid] = c.unas; w.j[par][wid] = c.j;
+}
+__device__ __forceinline__ Cand get_best(const WaveBest& w, int par, int k) {
+  Cand c;
+  c.v = w.v[par][k]; c.it = w.it[par][k]; c.unas = w.unas[par][k]; c.j = w.j[par][k];
+  return c;
 }
 
 // cost(i,j) of image b at cost[b*bs + i*rs + j*cs], i < nr (same for all images), j < nc[b]
 __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, long long bs, long long rs, long long cs, int nr_in,
                                               const int* __restrict__ nc_per, int nc_max, long long* __restrict__ row_idx,
                                               long long* __restrict__ col_idx, int kmax, int* __restrict__ count,
-                                              int* __restrict__ status, int R_cap, int C_cap) {
+                                              int* __restrict__ status, int R_cap, int C_cap, int cost_in_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* Cb = cost + (size_t)b * bs;
@@ -110,9 +134,10 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
   int* col4row = remaining + C_cap;                      // [R_cap]
   unsigned char* SR = reinterpret_cast<unsigned char*>(col4row + R_cap);  // [R_cap]
   unsigned char* SC = SR + R_cap;                        // [C_cap]
-  __shared__ Cand wbest[4];
-  __shared__ int s_ctl[4];  // 0: sink, 1: cur row i, 2: n_rem, 3: error
-  __shared__ double s_min;
+  // cost_in_lds: the oriented cost matrix [nr][nc] behind the solver state (every inner step reads one row of it: from LDS it
+  // costs an LDS read instead of an L2 round trip, on the serial critical path of the whole training step)
+  float* cl = reinterpret_cast<float*>(smem + (((size_t)R_cap * (8 + 4 + 1) + (size_t)C_cap * (8 + 8 + 4 + 4 + 4 + 1) + 15) & ~(size_t)15));
+  __shared__ WaveBest wbest;  // by step parity: a wave may be one step ahead of the slowest one
 
   if (nr == 0 || nc == 0) {
     if (tid == 0) { count[b] = 0; status[b] = 0; }
@@ -124,6 +149,7 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
     const int i = (int)(e / nc), j = (int)(e - (long long)i * nc);
     const float c = Cb[i * irs + j * ics];
     if (c != c || c == -INFINITY) bad = 1;
+    if (cost_in_lds) cl[e] = c;
   }
   bad = __syncthreads_or(bad);
   if (bad) {
@@ -132,58 +158,60 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
   }
   for (int i = tid; i < nr; i += 256) { u[i] = 0.0; col4row[i] = -1; }
   for (int j = tid; j < nc; j += 256) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
-  if (tid == 0) s_ctl[3] = 0;
   __syncthreads();
+  bool infeasible = false;
 
+  // One augmentation per row.  The shortest-path state of the inner loop (current row, remaining count, running minimum, sink) is
+  // UNIFORM and lives in registers: after the one barrier of a step every thread combines the four wave candidates itself, so
+  // there is no serial section and no broadcast barrier (two barriers and a thread-0 section per step before: the kernel is a
+  // chain of ~N^2/2 such steps on untrained models, whose 920 queries all want the same few columns).
+  int par = 0;
   for (int cur = 0; cur < nr; ++cur) {
     for (int j = tid; j < nc; j += 256) { remaining[j] = nc - j - 1; spc[j] = INFINITY; SC[j] = 0; }
     for (int i = tid; i < nr; i += 256) SR[i] = 0;
-    if (tid == 0) { s_ctl[0] = -1; s_ctl[1] = cur; s_ctl[2] = nc; s_min = 0.0; }
     __syncthreads();
+    int i = cur, n_rem = nc, sink = -1;
+    double min_val = 0.0;
     while (true) {
-      const int i = s_ctl[1], n_rem = s_ctl[2];
-      const double min_val = s_min, ui = u[i];
-      const float* Ci = Cb + i * irs;
+      const double ui = u[i];
+      const float* Ci = cost_in_lds ? cl + (size_t)i * nc : Cb + i * irs;
+      const long long cstep = cost_in_lds ? 1 : ics;
       Cand best;
-      best.v = INFINITY; best.it = -1; best.unas = 0;
+      best.v = INFINITY; best.it = -1; best.unas = 0; best.j = -1;
       for (int it = tid; it < n_rem; it += 256) {
         const int j = remaining[it];
-        const double r = ((min_val + (double)Ci[j * ics]) - ui) - v[j];
+        const double r = ((min_val + (double)Ci[j * cstep]) - ui) - v[j];
         double sj = spc[j];
         if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
         Cand c;
-        c.v = sj; c.it = it; c.unas = row4col[j] == -1;
+        c.v = sj; c.it = it; c.unas = row4col[j] == -1; c.j = j;
         best = better(best, c);
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) best = better(best, shfl_cand(best, off));
-      if (lane == 0) wbest[wid] = best;
-      __syncthreads();
-      if (tid == 0) {
-        SR[i] = 1;
-        Cand bb = better(better(wbest[0], wbest[1]), better(wbest[2], wbest[3]));
-        s_min = bb.v;
-        if (bb.it < 0 || bb.v == INFINITY) {
-          s_ctl[3] = 1;  // infeasible
-          s_ctl[0] = 0;
-        } else {
-          const int j = remaining[bb.it];
-          if (row4col[j] == -1) s_ctl[0] = j; else s_ctl[1] = row4col[j];
-          SC[j] = 1;
-          remaining[bb.it] = remaining[n_rem - 1];
-          s_ctl[2] = n_rem - 1;
-        }
-      }
-      __syncthreads();
-      if (s_ctl[0] != -1) break;
+      if (lane == 0) put_best(wbest, par, wid, best);
+      __syncthreads();  // candidates published; this step's spc / path writes ordered before the next step's reads
+      const Cand bb = better(better(get_best(wbest, par, 0), get_best(wbest, par, 1)), better(get_best(wbest, par, 2), get_best(wbest, par, 3)));
+      par ^= 1;
+      if (tid == 0) SR[i] = 1;
+      min_val = bb.v;
+      if (bb.it < 0 || bb.v == INFINITY) { infeasible = true; break; }
+      const int j = bb.j;
+      // position bb.it leaves the remaining set: its owner in the strided scan (it % 256) swaps the last position in, so the only
+      // thread that reads this slot next step is the one that wrote it
+      if ((bb.it & 255) == tid) remaining[bb.it] = remaining[n_rem - 1];
+      if (tid == 0) SC[j] = 1;
+      n_rem -= 1;
+      const int r4c = row4col[j];  // (row4col changes only in the augmentation below)
+      if (r4c == -1) { sink = j; break; }
+      i = r4c;
     }
-    if (s_ctl[3]) break;
-    const double min_val = s_min;
-    const int sink = s_ctl[0];
+    if (infeasible) break;
+    __syncthreads();  // SR / SC / spc of the last step visible to the dual update
     // dual update (reads spc / col4row of the pre-augmentation state)
-    for (int i = tid; i < nr; i += 256) {
-      if (i == cur) u[i] += min_val;
-      else if (SR[i]) u[i] += min_val - spc[col4row[i]];
+    for (int r = tid; r < nr; r += 256) {
+      if (r == cur) u[r] += min_val;
+      else if (SR[r]) u[r] += min_val - spc[col4row[r]];
     }
     for (int j = tid; j < nc; j += 256)
       if (SC[j]) v[j] -= min_val - spc[j];
@@ -191,18 +219,244 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
     if (tid == 0) {
       int j = sink;
       while (true) {
-        const int i = path[j];
-        row4col[j] = i;
-        const int t = col4row[i];
-        col4row[i] = j;
+        const int r = path[j];
+        row4col[j] = r;
+        const int t = col4row[r];
+        col4row[r] = j;
         j = t;
-        if (i == cur) break;
+        if (r == cur) break;
       }
     }
     __syncthreads();
   }
 
-  if (s_ctl[3]) {
+  if (infeasible) {
+    if (tid == 0) { count[b] = 0; status[b] = -1; }
+    return;
+  }
+  long long* ro = row_idx + (size_t)b * kmax;
+  long long* co = col_idx + (size_t)b * kmax;
+  if (!transpose) {
+    for (int i = tid; i < nr && i < kmax; i += 256) { ro[i] = i; co[i] = col4row[i]; }
+  } else if (tid == 0) {
+    int n = 0;
+    for (int j = 0; j < nc && n < kmax; ++j)
+      if (row4col[j] != -1) { ro[n] = j; co[n] = row4col[j]; ++n; }
+  }
+  if (tid == 0) { count[b] = nr < kmax ? nr : kmax; status[b] = 0; }
+}
+
+
+struct PCand {
+  double v;
+  int itj;
+  int r4;
+};
+
+__device__ __forceinline__ PCand pbetter(PCand a, PCand b) {
+  const int ai = a.itj >> 16, bi = b.itj >> 16;
+  const bool au = a.r4 < 0, bu = b.r4 < 0;
+  const bool b_wins = a.itj < 0 ? true
+                      : b.itj < 0 ? false
+                      : b.v < a.v ? true
+                      : a.v < b.v ? false
+                      : au != bu ? bu
+                      : au ? bi > ai   // last unassigned wins
+                           : bi < ai;  // first assigned stays
+  PCand r;
+  r.v = b_wins ? b.v : a.v;
+  r.itj = b_wins ? b.itj : a.itj;
+  r.r4 = b_wins ? b.r4 : a.r4;
+  return r;
+}
+
+// the candidate of the lane CTRL points at (DPP: VALU cross-lane moves, no LDS round trip as ds_bpermute / __shfl)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ PCand dpp_cand(PCand c) {
+  const unsigned long long vb = __builtin_bit_cast(unsigned long long, c.v);
+  const int lo = (int)(unsigned)vb, hi = (int)(unsigned)(vb >> 32);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  PCand r;
+  r.v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2);
+  r.itj = __builtin_amdgcn_update_dpp(c.itj, c.itj, CTRL, ROW_MASK, 0xF, false);
+  r.r4 = __builtin_amdgcn_update_dpp(c.r4, c.r4, CTRL, ROW_MASK, 0xF, false);
+  return r;
+}
+
+// best candidate of the wave, in every lane: rotations inside the 16-lane rows (pbetter is a minimum under a total order:
+// associative and commutative), row broadcasts across rows, the total from lane 63
+__device__ __forceinline__ PCand wave_best(PCand c) {
+  c = pbetter(c, dpp_cand<0x121, 0xF>(c));  // row_ror:1
+  c = pbetter(c, dpp_cand<0x122, 0xF>(c));  // row_ror:2
+  c = pbetter(c, dpp_cand<0x124, 0xF>(c));  // row_ror:4
+  c = pbetter(c, dpp_cand<0x128, 0xF>(c));  // row_ror:8
+  c = pbetter(c, dpp_cand<0x142, 0xA>(c));  // row_bcast:15 into rows 1, 3
+  c = pbetter(c, dpp_cand<0x143, 0xC>(c));  // row_bcast:31 into rows 2, 3
+  const unsigned long long vb = __builtin_bit_cast(unsigned long long, c.v);
+  PCand r;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)vb, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(vb >> 32), 63);
+  r.v = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  r.itj = __builtin_amdgcn_readlane(c.itj, 63);
+  r.r4 = __builtin_amdgcn_readlane(c.r4, 63);
+  return r;
+}
+
+// lsap_k with the per-column solver state in REGISTERS: thread t owns columns t, t + 256, ... (K of them: up to 1024 columns, the
+// 920 queries of the detection experts).  An inner step of lsap_k chases remaining[it] -> cost / v / spc / row4col of that column
+// through LDS, five dependent reads per position; here a step reads its cost entries (independent loads) and everything else --
+// v, the shortest-path cost, the row the column is assigned to, its position in scipy's `remaining` array -- is in registers,
+// with path / spc / row4col written through to LDS for the serial augmentation and the row dual update.  The position is what
+// scipy's tie rule is defined on (lowest value; ties: an unassigned column wins, the LAST unassigned or the FIRST assigned in
+// scan order), so it is tracked exactly: removing position p moves the column at the last position into p.  The wave reduction
+// runs on DPP moves, the four wave candidates are one 16-byte LDS entry each, and the winner carries its assigned row, so a
+// step is: cost loads -> scan -> DPP reduce -> LDS publish -> ONE barrier -> four LDS reads -> combine.  Same results as lsap_k
+// bit for bit; ~5000 -> ~2000 cycles per inner step, and an untrained detection head (every ground-truth box wants the same
+// queries) makes ~N^2 / 2 of them.
+template <int K>
+__global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost, long long bs, long long rs, long long cs, int nr_in,
+                                                  const int* __restrict__ nc_per, int nc_max, long long* __restrict__ row_idx,
+                                                  long long* __restrict__ col_idx, int kmax, int* __restrict__ count,
+                                                  int* __restrict__ status, int R_cap, int C_cap, int cost_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* Cb = cost + (size_t)b * bs;
+  const int nc_in = nc_per ? nc_per[b] : nc_max;
+  const bool transpose = nc_in < nr_in;
+  const int nr = transpose ? nc_in : nr_in;
+  const int nc = transpose ? nr_in : nc_in;
+  const long long irs = transpose ? cs : rs, ics = transpose ? rs : cs;
+
+  double* u = reinterpret_cast<double*>(smem);          // [R_cap]
+  double* v_unused = u + R_cap;                          // [C_cap] (layout shared with lsap_k)
+  double* spc = v_unused + C_cap;                        // [C_cap] write-through copy
+  int* path = reinterpret_cast<int*>(spc + C_cap);       // [C_cap]
+  int* row4col = path + C_cap;                           // [C_cap]
+  int* remaining = row4col + C_cap;                      // [C_cap]
+  int* col4row = remaining + C_cap;                      // [R_cap]
+  unsigned char* SR = reinterpret_cast<unsigned char*>(col4row + R_cap);  // [R_cap]
+  float* cl = reinterpret_cast<float*>(smem + (((size_t)R_cap * (8 + 4 + 1) + (size_t)C_cap * (8 + 8 + 4 + 4 + 4 + 1) + 15) & ~(size_t)15));
+  __shared__ __attribute__((aligned(16))) PCand wbest[2][4];  // by step parity: a wave may be one step ahead of the slowest one
+
+  if (nr == 0 || nc == 0) {
+    if (tid == 0) { count[b] = 0; status[b] = 0; }
+    return;
+  }
+  int bad = 0;
+  for (long long e = tid; e < (long long)nr * nc; e += 256) {
+    const int i = (int)(e / nc), j = (int)(e - (long long)i * nc);
+    const float c = Cb[i * irs + j * ics];
+    if (c != c || c == -INFINITY) bad = 1;
+    if (cost_in_lds) cl[e] = c;
+  }
+  bad = __syncthreads_or(bad);
+  if (bad) {
+    if (tid == 0) { count[b] = 0; status[b] = -2; }
+    return;
+  }
+  for (int i = tid; i < nr; i += 256) { u[i] = 0.0; col4row[i] = -1; }
+  double vj[K], sp[K];
+  int pos[K], r4c[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int j = tid + 256 * k;
+    vj[k] = 0.0;
+    r4c[k] = -1;
+    if (j < nc) { row4col[j] = -1; path[j] = -1; }
+  }
+  __syncthreads();
+  bool infeasible = false;
+  int par = 0;
+  for (int cur = 0; cur < nr; ++cur) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int j = tid + 256 * k;
+      pos[k] = j < nc ? nc - 1 - j : -1;   // remaining[it] = nc - it - 1
+      sp[k] = INFINITY;
+      if (j < nc) { remaining[nc - 1 - j] = j; spc[j] = INFINITY; }
+    }
+    for (int i = tid; i < nr; i += 256) SR[i] = 0;
+    __syncthreads();
+    int i = cur, n_rem = nc, sink = -1, pbit = -1, pjl = -1;
+    double min_val = 0.0;
+    while (true) {
+      const double ui = u[i];
+      // the column at the last position fills the hole this step leaves.  Read early (off the critical path); the one slot the
+      // previous step's owner thread may still be writing is known from registers
+      const int jl_lds = remaining[n_rem - 1];
+      const int jl = pbit == n_rem - 1 ? pjl : jl_lds;
+      const float* Ci = cost_in_lds ? cl + (size_t)i * nc : Cb + i * irs;
+      const long long cstep = cost_in_lds ? 1 : ics;
+      float cv[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) cv[k] = pos[k] >= 0 ? Ci[(long long)(tid + 256 * k) * cstep] : 0.f;
+      PCand cand[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        cand[k].v = INFINITY; cand[k].itj = -1; cand[k].r4 = 0;
+        if (pos[k] >= 0) {
+          const int j = tid + 256 * k;
+          const double r = ((min_val + (double)cv[k]) - ui) - vj[k];
+          if (r < sp[k]) { sp[k] = r; path[j] = i; spc[j] = r; }
+          cand[k].v = sp[k]; cand[k].itj = (pos[k] << 16) | j; cand[k].r4 = r4c[k];
+        }
+      }
+      PCand best = cand[0];
+      if (K == 4) best = pbetter(pbetter(cand[0], cand[1]), pbetter(cand[2], cand[3]));
+      else
+#pragma unroll
+        for (int k = 1; k < K; ++k) best = pbetter(best, cand[k]);
+      best = wave_best(best);
+      if (lane == 0) wbest[par][wid] = best;
+      __syncthreads();
+      const PCand bb = pbetter(pbetter(wbest[par][0], wbest[par][1]), pbetter(wbest[par][2], wbest[par][3]));
+      par ^= 1;
+      if (tid == 0) SR[i] = 1;
+      min_val = bb.v;
+      if (bb.itj < 0 || bb.v == INFINITY) { infeasible = true; break; }
+      const int bit = bb.itj >> 16, bj = bb.itj & 0xffff;
+      // position bit leaves the remaining set; the column at the last position moves into it
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int j = tid + 256 * k;
+        if (j == bj) pos[k] = -1;                      // removed (= in SC)
+        else if (j == jl) { pos[k] = bit; remaining[bit] = jl; }
+      }
+      n_rem -= 1;
+      pbit = bit; pjl = jl;
+      if (bb.r4 < 0) { sink = bj; break; }
+      i = bb.r4;
+    }
+    if (infeasible) break;
+    __syncthreads();  // SR / spc / path of the last step visible
+    for (int r = tid; r < nr; r += 256) {
+      if (r == cur) u[r] += min_val;
+      else if (SR[r]) u[r] += min_val - spc[col4row[r]];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (pos[k] < 0 && tid + 256 * k < nc) vj[k] -= min_val - sp[k];   // columns in SC
+    __syncthreads();
+    if (tid == 0) {
+      int j = sink;
+      while (true) {
+        const int r = path[j];
+        row4col[j] = r;
+        const int t = col4row[r];
+        col4row[r] = j;
+        j = t;
+        if (r == cur) break;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int j = tid + 256 * k;
+      if (j < nc) r4c[k] = row4col[j];
+    }
+  }
+
+  if (infeasible) {
     if (tid == 0) { count[b] = 0; status[b] = -1; }
     return;
   }
@@ -251,15 +505,30 @@ extern "C" int am_lsap_batched(const float* cost, int B, int nr, const int32_t* 
   if (!cost && nr > 0 && nc_max > 0) return AM_ERR_ARG;
   const int R_cap = ((nr < nc_max ? nr : nc_max) + 7) & ~7;  // rows after orienting wide, worst case
   const int C_cap = ((nr > nc_max ? nr : nc_max) + 7) & ~7;
-  const size_t lds = (size_t)R_cap * (8 + 4 + 1) + (size_t)C_cap * (8 + 8 + 4 + 4 + 4 + 1) + 64;
-  if (lds > 150 * 1024) return AM_ERR_UNSUPPORTED;
+  const size_t state = (((size_t)R_cap * (8 + 4 + 1) + (size_t)C_cap * (8 + 8 + 4 + 4 + 4 + 1) + 15) & ~(size_t)15);
+  if (state + 64 > 150 * 1024) return AM_ERR_UNSUPPORTED;
+  // the oriented cost matrix rides in LDS when it fits beside the solver state (920 queries x up to ~34 boxes)
+  const size_t cost_bytes = (size_t)R_cap * C_cap * 4;
+  const int cost_in_lds = state + cost_bytes + 64 <= 156 * 1024;
+  const size_t lds = state + (cost_in_lds ? cost_bytes : 0) + 64;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return AM_ERR_LAUNCH;
   }
+  if (C_cap <= 1024) {  // columns after orienting wide fit four per thread: solver state in registers
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_reg_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return AM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(lsap_reg_k<4>, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), cost, batch_stride, row_stride, col_stride,
+                       nr, (const int*)nc_per, nc_max, (long long*)row_idx, (long long*)col_idx, kmax, (int*)count, (int*)status,
+                       R_cap, C_cap, cost_in_lds);
+    AM_CHECK_LAUNCH();
+    return AM_OK;
+  }
   hipLaunchKernelGGL(lsap_k, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), cost, batch_stride, row_stride, col_stride,
                      nr, (const int*)nc_per, nc_max, (long long*)row_idx, (long long*)col_idx, kmax, (int*)count, (int*)status,
-                     R_cap, C_cap);
+                     R_cap, C_cap, cost_in_lds);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

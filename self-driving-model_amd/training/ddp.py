@@ -170,7 +170,7 @@ class GradBucketReducer:
         return int(t.item())
 
 
-def _quiesce_collectives(reducer: "GradBucketReducer"):
+def quiesce_collectives(reducer: "GradBucketReducer"):
     """Before a capture begins: every eager collective issued so far (the mode agreement, earlier steps' buckets) has finished AND
     has been reaped by the process group's watchdog thread, so that thread has no event left to poll while this thread captures.
     (c10d's watchdog calls hipEventQuery on the events of outstanding work about every 100 ms; a query that lands inside
@@ -197,7 +197,7 @@ def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step
         reducer.paused = reducer.enabled and want == 1
         reducer.reset()
         got = want
-        _quiesce_collectives(reducer)
+        quiesce_collectives(reducer)
         try:
             graph, result = capture_fn(want == 2)
         except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back, loudly)

@@ -19,7 +19,7 @@ import torch.nn.functional as F  # noqa: F401  (kept for API parity with the ref
 from .. import runtime
 from ..models.automoe import create_automoe_model
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached, quiesce_collectives
 from .optim import FusedAdamW
 
 
@@ -150,6 +150,7 @@ class GatingTrainStep:
         mode = "thread_local" if self.reducer.enabled else "global"
         cache_b = None
         try:
+            quiesce_collectives(self.reducer)  # (the expert graph below is captured outside capture_step)
             if (self.prefetch_experts and hasattr(self.core, "forward_experts") and self.core.fuse_expert_pooling
                     and self.core.experts_frozen() and batch["image"].is_cuda):
                 self._expert_stream = torch.cuda.Stream(device=batch["image"].device)
