@@ -29,3 +29,14 @@ for (B, H, W, cin, cout) in [(32, 90, 160, 128, 128), (16, 90, 160, 128, 128), (
         L.am_set_tuning(lib.AM_TUNE_HALO_MIN_TILES, old)
         res.append(f"{hc.CONV_KERNEL_NAMES.get(k, k)} {us:7.1f} us {fl / us / 1e6:6.0f} TF/s")
     print(f"B={B} {H}x{W} {cin}->{cout}: " + "   |   ".join(res), flush=True)
+# PRE form (BatchNorm + ReLU of the producing layer applied to the staged patch) against the plain form
+import ctypes
+for (B, H, W, cin, cout) in [(32, 90, 160, 128, 128)]:
+    s = hc.ConvSpec(cin, cout, 3, 1, 1)
+    x = torch.randn(B, H, W, cin, device=dev).to(dt); w = torch.randn(cout, cin, 3, 3, device=dev) / 34; wp = hc.pack_fwd(w, s, dt)
+    y = torch.empty(B, H, W, cout, dtype=dt, device=dev); stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=dev)
+    sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev)
+    g = hc.fwd_geom(s, B, H, W, cin, cout, 2)
+    us_pre = t(lambda: L.am_conv_gemm_prebn(ctypes.byref(g), 1, hc.ptr(x), hc.ptr(sc), hc.ptr(sh), hc.ptr(wp), hc.ptr(y), hc.ptr(stats), hc.stream()))
+    us_plain = t(lambda: hc.conv_gemm(g, x, wp, None, False, y, stats))
+    print(f"B={B} {H}x{W} {cin}->{cout}: conv_halo_k<PRE> {us_pre:7.1f} us   plain {us_plain:7.1f} us", flush=True)

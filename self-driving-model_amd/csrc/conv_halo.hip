@@ -87,7 +87,6 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
   // which the counted vmcnt waits rely on
   unsigned pvo[PSLOTS];
   int pdst[PSLOTS];
-  int pcc = 0;  // 2 bits per slot: the 16-byte channel chunk of this lane's granule (PRE)
 #pragma unroll
   for (int s = 0; s < PSLOTS; ++s) {
     int piece = s * 8 + wid;
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
     const bool ok = cc < 4 && pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     pvo[s] = ok ? (unsigned)((((img * p.H + iy) * p.W + ix) * p.ldi + p.x_coff) * 2 + cc * 16) : OOB;
     pdst[s] = piece * 1024;
-    pcc |= (cc & 3) << (2 * s);
   }
   const int own_slots = wid < NPIECE - 8 * (PSLOTS - 1) ? PSLOTS : PSLOTS - 1;  // slots whose piece this wave transforms (PRE)
   // weights: this wave's 16 rows of the 128-row tile, one piece per K-step
@@ -127,24 +125,30 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
   // PRE: relu(x * scale + shift) on this wave's granules of the patch of `chunk` in buffer `buf` (after the wave's own vmcnt
   // wait, before the barrier that publishes the patch); out-of-image granules stay zero
   float* aff = reinterpret_cast<float*>(smem + AFF_BASE);  // [2][MAX_PRE_C]
-  auto transform = [&](int chunk, int buf) {
-#pragma unroll
-    for (int s = 0; s < PSLOTS; ++s) {
+  auto transform_slot = [&](int s, int chunk, int buf) {
+    {
       if (s < own_slots && pvo[s] != OOB) {
-        half8_t* slot = reinterpret_cast<half8_t*>(smem + buf * PATCH_BYTES + pdst[s] + lane * 16);
-        const int c0 = chunk * 32 + ((pcc >> (2 * s)) & 3) * 8;
-        const half8_t v = *slot;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + c0), s1 = *reinterpret_cast<const f32x4*>(aff + c0 + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + MAX_PRE_C + c0), h1 = *reinterpret_cast<const f32x4*>(aff + MAX_PRE_C + c0 + 4);
-        half8_t o;
+        // (in two halves of four channels, each finished before the next is loaded: the kernel sits at its 128-register budget --
+        // four waves per SIMD -- and a spill reload next to the LDS-DMA costs a vmcnt(0): 21 spills made this form 27 % slower)
+        half4_t* slot4 = reinterpret_cast<half4_t*>(smem + buf * PATCH_BYTES + pdst[s] + lane * 16);
+        const int c0 = chunk * 32 + (int)((pvo[s] >> 4) & 3u) * 8;  // (PRE: x_coff = 0 and whole pixels of 64-byte multiples: bits 4-5 are the chunk)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (half_t)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
-          o[4 + e] = (half_t)fmaxf((float)v[4 + e] * s1[e] + h1[e], 0.f);
+        for (int h = 0; h < 2; ++h) {
+          const half4_t v = slot4[h];
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + c0 + 4 * h);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + MAX_PRE_C + c0 + 4 * h);
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf((float)v[e] * sc[e] + sh[e], 0.f);
+          slot4[h] = o;
+          asm volatile("" ::: "memory");
         }
-        *slot = o;
       }
     }
+  };
+  auto transform = [&](int chunk, int buf) {
+#pragma unroll
+    for (int s = 0; s < PSLOTS; ++s) transform_slot(s, chunk, buf);
   };
   if (PRE) {
     for (int i = tid; i < p.Cin; i += NTH) {
@@ -194,17 +198,24 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
       const int ky = t / 3, kx = t - ky * 3;
       const int stage = t % 3, nstage = (t + 1) % 3, istage = (t + 2) % 3;
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments read half a K-step ago
+      if (PRE && t >= 4 && t < 4 + PSLOTS) {
+        // the next chunk's patch piece of slot t - 4 was issued on tap t - 4: 6 - (t - 4) newer pieces since (one transform per
+        // K-step on taps 4..7 instead of four on one: the rewrite sits under the other waves' MFMAs).  Published by the barrier of
+        // tap 7 at the latest, first read behind the barrier of tap 8.  Placed where only half of the fragment registers are
+        // live (before this K-step's second-half fragments are requested): the kernel sits at its 128-register budget, and a
+        // spill reload next to the LDS-DMA costs a vmcnt(0) -- 21 spills made this form 27 % slower than it had to be
+        if (t == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (t == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (t == 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (c + 1 < nchunk) transform_slot(t - 4, c + 1, (c + 1) & 1);
+      }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) a1[tm] = *reinterpret_cast<const half8_t*>(P + ((tm + ky) * PW + kx) * PP + 32);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) b1[tn] = *reinterpret_cast<const half8_t*>(smem + fb[1] + stage * BSTAGE + tn * 32 * BKB);
       // weight tile kk+2 into the stage of tile kk-1 (everyone finished reading it before the last barrier); patch piece of the
       // next chunk into the other patch buffer (last read during the previous chunk)
-      if (PRE && t == 7) {
-        // the next chunk's patch pieces were issued on taps 0..3; only the weight pieces of taps 4..6 are newer
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        if (c + 1 < nchunk) transform(c + 1, (c + 1) & 1);  // published by this K-step's barrier, first read after the next one
-      }
       if (t + 2 < 9) issue_b(t + 2, c, istage);
       else issue_b(t + 2 - 9, c + 1, istage);
       if (t < PSLOTS) issue_patch(t, c + 1, (c + 1) & 1);
