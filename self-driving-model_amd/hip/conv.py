@@ -750,12 +750,17 @@ def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
     """ResNet stem for a FROZEN trunk in train-mode BatchNorm: conv7x7/s2 -> BN(batch statistics, running stats
     updated) -> ReLU -> MaxPool(3,2,1) as two passes over the space-to-depth image -- a statistics-only pass and a pass
     whose epilogue normalises, rectifies and pools -- so neither the raw conv output nor the normalised map ever reaches
-    HBM.  Returns the pooled NHWC activation, or None when the case is not covered (caller runs the unfused sequence)."""
+    HBM.  Eval-mode BatchNorm (inference): the second pass alone, with scale / shift from the running statistics.
+    Returns the pooled NHWC activation, or None when the case is not covered (caller runs the unfused sequence)."""
     import ctypes
     s = cfg.spec
-    if not (FUSE_FIRST_LAYER and s.first and x.dtype == torch.float16 and bn is not None and bn.training and s.cout == 64):
+    if not (FUSE_FIRST_LAYER and s.first and x.dtype == torch.float16 and bn is not None and s.cout == 64):
         return None
-    if conv_w.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad:
+    # train-mode BatchNorm: only a frozen stem (no gradient through the fused passes); eval mode (inference: running statistics
+    # are constants, no statistics pass): whenever nothing asks for a gradient
+    if (conv_w.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad) and (bn.training or torch.is_grad_enabled()):
+        return None
+    if not bn.training and bn.running_mean is None:
         return None
     orig_hw = cfg.orig_hw or getattr(x, "orig_hw", None)
     if orig_hw is None:
@@ -769,29 +774,39 @@ def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
     P = B * OH * OW
     dev = x.device
     wp = cfg.cache.get_fwd(conv_w, s, x.dtype)
-    stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
-    try:
-        _timed("conv_gemm", 0.0, lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 1, ptr(x), ptr(wp), None, None, None,
-                                                               ptr(stats), stream()))
-    except RuntimeError as e:
-        if "UNSUPPORTED" not in str(e):
-            raise
-        return None
     scale = torch.empty(64, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
-    momentum = bn.momentum if bn.momentum is not None else 0.1
-    upd = bn.track_running_stats and bn.running_mean is not None
-    L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
-                     ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum),
-                     float(bn.eps), 1, ptr(scale), ptr(shift), None, None, 64, stream())
-    if upd:
-        _runtime().bump_stats_epoch()
-    if upd and bn.num_batches_tracked is not None:
-        PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+    if bn.training:
+        stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
+        try:
+            _timed("conv_gemm", 0.0, lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 1, ptr(x), ptr(wp), None, None, None,
+                                                                   ptr(stats), stream()))
+        except RuntimeError as e:
+            if "UNSUPPORTED" not in str(e):
+                raise
+            return None
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        upd = bn.track_running_stats and bn.running_mean is not None
+        L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias),
+                         ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum),
+                         float(bn.eps), 1, ptr(scale), ptr(shift), None, None, 64, stream())
+        if upd:
+            _runtime().bump_stats_epoch()
+        if upd and bn.num_batches_tracked is not None:
+            PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+    else:
+        # eval mode: scale / shift from the running statistics (am_bn_finalize's eval branch), ONE pass over the image
+        L.am_bn_finalize(None, AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                         0.0, float(bn.eps), 0, ptr(scale), ptr(shift), None, None, 64, stream())
     POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
     y = torch.empty((B, POH, POW, 64), dtype=x.dtype, device=dev)
-    _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * 64,
-           lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 3, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(y), None, stream()))
+    try:
+        _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * 64,
+               lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 3, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(y), None, stream()))
+    except RuntimeError as e:
+        if "UNSUPPORTED" not in str(e) or bn.training:
+            raise
+        return None
     return y
 
 

@@ -888,6 +888,50 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
 
 
+def test_eval_mode_stem_runs_conv_bn_relu_maxpool_as_one_pass():
+    """Inference (eval-mode BatchNorm): the ResNet stem conv7x7/s2 -> BN(running statistics) -> ReLU -> MaxPool(3,2,1) is ONE pass
+    over the space-to-depth image (am_conv_first_fused mode 3 with scale / shift from the running statistics) instead of conv
+    (+ folded BN + ReLU) -> full-resolution map -> max-pool pass; against the unfused sequence and the torch oracle."""
+    from conftest import launched_kernel
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    from self_driving_model_amd.models.experts.resnet import Trunk
+    import oracle.torch_ref as tref
+    dev = _dev()
+    img = seeded_tensor((2, 3, 448, 640), 51)  # 2 x 224 x 320 conv outputs: above the patch kernel's 64 k-pixel gate
+    trunk = seed_module_(Trunk(), 52).to(dev).eval()
+    outs = {}
+    for fused in (True, False):
+        hc.FUSE_FIRST_LAYER = fused
+        try:
+            with runtime.precision(torch.float16, 1.0), torch.no_grad():
+                runtime.begin_step(dev)
+                x = hops.image_to_s2d(img.to(dev), torch.float16)
+                # the stem + pool through Trunk's own dispatch, stopping before layer1
+                cfg = hc._Cfg(trunk[0].spec, trunk[0]._packed, trunk[1], True, 1.0, getattr(x, "orig_hw", None))
+                pooled = hc.fused_stem_pool(x, trunk[0].weight, trunk[1], cfg)
+                if fused:
+                    assert pooled is not None
+                    launched_kernel("conv_s2d_pool_k", what="eval-mode stem")
+                else:
+                    assert pooled is None
+                    from self_driving_model_amd.models._nn import conv_bn_act
+                    pooled = trunk[3](conv_bn_act(x, trunk[0], trunk[1], relu=True))
+                outs[fused] = pooled.float().cpu()
+        finally:
+            hc.FUSE_FIRST_LAYER = True
+    assert outs[True].shape == outs[False].shape == (2, 112, 160, 64)
+    assert rel_err(outs[True], outs[False]) < 2e-3
+    ref = tref.resnet18_trunk() if hasattr(tref, "resnet18_trunk") else None
+    if ref is not None:
+        ref.load_state_dict({k: v.cpu() for k, v in trunk.state_dict().items()})
+        ref.eval()
+        with torch.no_grad():
+            r = ref[3](ref[2](ref[1](ref[0](img))))
+        assert rel_err(outs[True].permute(0, 3, 1, 2), r) < 3e-3
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_conv_packs_rebuilt_by_one_launch_per_step(use_graph):
     """FusedAdamW.attach_conv_packs: every trainable conv layer's packed operands (forward + input-gradient layouts) come from
