@@ -199,16 +199,18 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
       const int stage = t % 3, nstage = (t + 1) % 3, istage = (t + 2) % 3;
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments read half a K-step ago
       if (PRE && t >= 4 && t < 4 + PSLOTS) {
-        // the next chunk's patch piece of slot t - 4 was issued on tap t - 4: 6 - (t - 4) newer pieces since (one transform per
-        // K-step on taps 4..7 instead of four on one: the rewrite sits under the other waves' MFMAs).  Published by the barrier of
-        // tap 7 at the latest, first read behind the barrier of tap 8.  Placed where only half of the fragment registers are
-        // live (before this K-step's second-half fragments are requested): the kernel sits at its 128-register budget, and a
-        // spill reload next to the LDS-DMA costs a vmcnt(0) -- 21 spills made this form 27 % slower than it had to be
-        if (t == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (t == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (t == 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        if (c + 1 < nchunk) transform_slot(t - 4, c + 1, (c + 1) & 1);
+        // One slot of the next chunk's patch per K-step on taps 4..7 (instead of four on one: the rewrite sits under the other
+        // waves' MFMAs), placed where only half of the fragment registers are live (before this K-step's second-half fragments
+        // are requested): the kernel sits at its 128-register budget, and a spill reload next to the LDS-DMA costs a vmcnt(0)
+        // -- 21 spills made this form 27 % slower than it had to be.  Order: slots 1, 2, 3, then 0 -- waves 3..7 fetch their
+        // slot-0 piece a second time on tap 3 (see the loader state), so slot 0 is rewritten only once that copy has landed too.
+        // Slot s was issued on tap s behind that tap's weight piece; the counts below are the pieces issued after it.
+        // Published by the barrier of tap 7, first read behind the barrier of tap 8.
+        if (t == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // slot 1: taps 2, 3 (two pieces each)
+        else if (t == 5) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // slot 2: tap 3 (two), tap 4
+        else if (t == 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // slot 3: taps 4, 5
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");              // slot 0 and its second copy (tap 3): taps 4, 5, 6
+        if (c + 1 < nchunk) transform_slot(t == 7 ? 0 : t - 3, c + 1, (c + 1) & 1);
       }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) a1[tm] = *reinterpret_cast<const half8_t*>(P + ((tm + ky) * PW + kx) * PP + 32);

@@ -1035,7 +1035,9 @@ def test_frozen_basic_block_fused_bn_matches_unfused(C, shape, kernel):
             hc.flush_bn_counters()
         outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
     hc.FUSE_BLOCK_BN = True
-    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    # same fp32 arithmetic on the same f16 operands, same kernel for conv2: bit-identical up to the statistics' summation order
+    # (a patch element transformed twice, or not at all, shows up as ~1e-3 here: a loose bound would hide a race in the staging)
+    assert rel_err(outs[True][0], outs[False][0]) < 1e-5
     for k, v in outs[False][1].items():
         close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
     assert int(outs[True][1]["bn1.num_batches_tracked"]) == 1 and int(outs[True][1]["bn2.num_batches_tracked"]) == 1
@@ -1064,7 +1066,7 @@ def test_frozen_strided_block_conv2_takes_bn1_in_its_input_staging():
             hc.flush_bn_counters()
         outs[fused] = (y.float(), {k: v.clone() for k, v in blk.state_dict().items()})
     hc.FUSE_BLOCK_BN = True
-    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    assert rel_err(outs[True][0], outs[False][0]) < 1e-5  # (bit-identical up to the statistics' summation order: see the identity-block test)
     for k, v in outs[False][1].items():
         close(outs[True][1][k].float(), v.float(), rtol=2e-3, atol=2e-4, what=k)
 
