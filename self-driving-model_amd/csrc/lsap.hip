@@ -174,13 +174,14 @@ __global__ __launch_bounds__(256) void lsap_k(const float* __restrict__ cost, lo
     double min_val = 0.0;
     while (true) {
       const double ui = u[i];
-      const float* Ci = cost_in_lds ? cl + (size_t)i * nc : Cb + i * irs;
-      const long long cstep = cost_in_lds ? 1 : ics;
+      const float* Cl = cl + (size_t)i * nc;
+      const float* Cg = Cb + i * irs;
       Cand best;
       best.v = INFINITY; best.it = -1; best.unas = 0; best.j = -1;
       for (int it = tid; it < n_rem; it += 256) {
         const int j = remaining[it];
-        const double r = ((min_val + (double)Ci[j * cstep]) - ui) - v[j];
+        const float cij = cost_in_lds ? Cl[j] : Cg[j * ics];  // (typed loads: no generic pointer)
+        const double r = ((min_val + (double)cij) - ui) - v[j];
         double sj = spc[j];
         if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
         Cand c;
@@ -313,11 +314,11 @@ __device__ __forceinline__ PCand wave_best(PCand c) {
 // step is: cost loads -> scan -> DPP reduce -> LDS publish -> ONE barrier -> four LDS reads -> combine.  Same results as lsap_k
 // bit for bit; ~5000 -> ~2000 cycles per inner step, and an untrained detection head (every ground-truth box wants the same
 // queries) makes ~N^2 / 2 of them.
-template <int K>
+template <int K, bool COST_LDS>
 __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost, long long bs, long long rs, long long cs, int nr_in,
                                                   const int* __restrict__ nc_per, int nc_max, long long* __restrict__ row_idx,
                                                   long long* __restrict__ col_idx, int kmax, int* __restrict__ count,
-                                                  int* __restrict__ status, int R_cap, int C_cap, int cost_in_lds) {
+                                                  int* __restrict__ status, int R_cap, int C_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* Cb = cost + (size_t)b * bs;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
     const int i = (int)(e / nc), j = (int)(e - (long long)i * nc);
     const float c = Cb[i * irs + j * ics];
     if (c != c || c == -INFINITY) bad = 1;
-    if (cost_in_lds) cl[e] = c;
+    if (COST_LDS) cl[e] = c;
   }
   bad = __syncthreads_or(bad);
   if (bad) {
@@ -385,11 +386,18 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
       // previous step's owner thread may still be writing is known from registers
       const int jl_lds = remaining[n_rem - 1];
       const int jl = pbit == n_rem - 1 ? pjl : jl_lds;
-      const float* Ci = cost_in_lds ? cl + (size_t)i * nc : Cb + i * irs;
-      const long long cstep = cost_in_lds ? 1 : ics;
+      // (two typed paths: one pointer that may be LDS or global is a generic pointer -- flat_load, the slow path, on the
+      // critical chain of every step)
       float cv[K];
+      if (COST_LDS) {
+        const float* Ci = cl + i * nc;
 #pragma unroll
-      for (int k = 0; k < K; ++k) cv[k] = pos[k] >= 0 ? Ci[(long long)(tid + 256 * k) * cstep] : 0.f;
+        for (int k = 0; k < K; ++k) cv[k] = pos[k] >= 0 ? Ci[tid + 256 * k] : 0.f;
+      } else {
+        const float* Ci = Cb + i * irs;
+#pragma unroll
+        for (int k = 0; k < K; ++k) cv[k] = pos[k] >= 0 ? Ci[(long long)(tid + 256 * k) * ics] : 0.f;
+      }
       PCand cand[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -516,13 +524,13 @@ extern "C" int am_lsap_batched(const float* cost, int B, int nr, const int32_t* 
     if (e != hipSuccess) return AM_ERR_LAUNCH;
   }
   if (C_cap <= 1024) {  // columns after orienting wide fit four per thread: solver state in registers
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_reg_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return AM_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(lsap_reg_k<4>, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), cost, batch_stride, row_stride, col_stride,
-                       nr, (const int*)nc_per, nc_max, (long long*)row_idx, (long long*)col_idx, kmax, (int*)count, (int*)status,
-                       R_cap, C_cap, cost_in_lds);
+    const void* fn = cost_in_lds ? reinterpret_cast<const void*>(lsap_reg_k<4, true>) : reinterpret_cast<const void*>(lsap_reg_k<4, false>);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AM_ERR_LAUNCH;
+#define AM_LSAP_ARGS cost, batch_stride, row_stride, col_stride, nr, (const int*)nc_per, nc_max, (long long*)row_idx, (long long*)col_idx, kmax, \
+                     (int*)count, (int*)status, R_cap, C_cap
+    if (cost_in_lds) hipLaunchKernelGGL((lsap_reg_k<4, true>), dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), AM_LSAP_ARGS);
+    else hipLaunchKernelGGL((lsap_reg_k<4, false>), dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), AM_LSAP_ARGS);
+#undef AM_LSAP_ARGS
     AM_CHECK_LAUNCH();
     return AM_OK;
   }
