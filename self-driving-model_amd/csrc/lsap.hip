@@ -285,21 +285,71 @@ __device__ __forceinline__ PCand dpp_cand(PCand c) {
   return r;
 }
 
-// best candidate of the wave, in every lane: rotations inside the 16-lane rows (pbetter is a minimum under a total order:
-// associative and commutative), row broadcasts across rows, the total from lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false); }
+
+// Best candidate of the wave, in every lane.  The value decides almost every step, so only the VALUE is reduced across the
+// lanes (v_min_f64 on DPP moves: rotations inside the 16-lane rows, row broadcasts across rows, the total from lane 63); the
+// lanes that hold the minimum are a ballot, and in the common case of one such lane its position / column / assigned row are
+// three readlanes.  Several lanes at the minimum (exact ties: scipy's rule decides): a second, integer, reduction of the tie key.
 __device__ __forceinline__ PCand wave_best(PCand c) {
-  c = pbetter(c, dpp_cand<0x121, 0xF>(c));  // row_ror:1
-  c = pbetter(c, dpp_cand<0x122, 0xF>(c));  // row_ror:2
-  c = pbetter(c, dpp_cand<0x124, 0xF>(c));  // row_ror:4
-  c = pbetter(c, dpp_cand<0x128, 0xF>(c));  // row_ror:8
-  c = pbetter(c, dpp_cand<0x142, 0xA>(c));  // row_bcast:15 into rows 1, 3
-  c = pbetter(c, dpp_cand<0x143, 0xC>(c));  // row_bcast:31 into rows 2, 3
-  const unsigned long long vb = __builtin_bit_cast(unsigned long long, c.v);
+  double m = c.v;
+  m = fmin(m, dpp_f64<0x121, 0xF>(m));  // row_ror:1
+  m = fmin(m, dpp_f64<0x122, 0xF>(m));  // row_ror:2
+  m = fmin(m, dpp_f64<0x124, 0xF>(m));  // row_ror:4
+  m = fmin(m, dpp_f64<0x128, 0xF>(m));  // row_ror:8
+  m = fmin(m, dpp_f64<0x142, 0xA>(m));  // row_bcast:15 into rows 1, 3
+  m = fmin(m, dpp_f64<0x143, 0xC>(m));  // row_bcast:31 into rows 2, 3
+  const unsigned long long mb = __builtin_bit_cast(unsigned long long, m);
+  const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mb, 63), mhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mb >> 32), 63);
+  const double vmin = __builtin_bit_cast(double, ((unsigned long long)mhi << 32) | mlo);
+  const bool at_min = c.itj >= 0 && c.v == vmin;
+  unsigned long long mask = __ballot(at_min);
   PCand r;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)vb, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(vb >> 32), 63);
-  r.v = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-  r.itj = __builtin_amdgcn_readlane(c.itj, 63);
-  r.r4 = __builtin_amdgcn_readlane(c.r4, 63);
+  r.v = INFINITY; r.itj = -1; r.r4 = 0;
+  if (mask == 0) return r;  // no candidate at all
+  if (mask & (mask - 1)) {
+    // ties: smaller key wins -- unassigned before assigned; among unassigned the LAST position, among assigned the FIRST
+    const int it = c.itj >> 16;
+    int key = !at_min ? 0x7fffffff : (c.r4 < 0 ? 0x7fff - it : 0x10000 + it);
+    key = min(key, dpp_i32<0x121, 0xF>(key));
+    key = min(key, dpp_i32<0x122, 0xF>(key));
+    key = min(key, dpp_i32<0x124, 0xF>(key));
+    key = min(key, dpp_i32<0x128, 0xF>(key));
+    key = min(key, dpp_i32<0x142, 0xA>(key));
+    key = min(key, dpp_i32<0x143, 0xC>(key));
+    const int kmin = __builtin_amdgcn_readlane(key, 63);
+    const int mykey = !at_min ? 0x7fffffff : (c.r4 < 0 ? 0x7fff - it : 0x10000 + it);
+    mask = __ballot(mykey == kmin);
+  }
+  const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mask) - 1);
+  r.v = vmin;
+  r.itj = __builtin_amdgcn_readlane(c.itj, src);
+  r.r4 = __builtin_amdgcn_readlane(c.r4, src);
+  return r;
+}
+
+// pbetter over four candidates: minimum value first (three v_min_f64), then the tie key among those at the minimum
+__device__ __forceinline__ PCand pbest4(PCand a, PCand b, PCand c, PCand d) {
+  const double vmin = fmin(fmin(a.v, b.v), fmin(c.v, d.v));
+  auto key = [&](const PCand& x) { return (x.itj < 0 || x.v != vmin) ? 0x7fffffff : (x.r4 < 0 ? 0x7fff - (x.itj >> 16) : 0x10000 + (x.itj >> 16)); };
+  const int ka = key(a), kb = key(b), kc = key(c), kd = key(d);
+  const int kmin = min(min(ka, kb), min(kc, kd));
+  PCand r;
+  r.v = INFINITY; r.itj = -1; r.r4 = 0;
+  if (kmin != 0x7fffffff) {
+    r.v = vmin;
+    r.itj = ka == kmin ? a.itj : kb == kmin ? b.itj : kc == kmin ? c.itj : d.itj;
+    r.r4 = ka == kmin ? a.r4 : kb == kmin ? b.r4 : kc == kmin ? c.r4 : d.r4;
+  }
   return r;
 }
 
@@ -410,14 +460,14 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
         }
       }
       PCand best = cand[0];
-      if (K == 4) best = pbetter(pbetter(cand[0], cand[1]), pbetter(cand[2], cand[3]));
+      if (K == 4) best = pbest4(cand[0], cand[1], cand[2], cand[3]);
       else
 #pragma unroll
         for (int k = 1; k < K; ++k) best = pbetter(best, cand[k]);
       best = wave_best(best);
       if (lane == 0) wbest[par][wid] = best;
       __syncthreads();
-      const PCand bb = pbetter(pbetter(wbest[par][0], wbest[par][1]), pbetter(wbest[par][2], wbest[par][3]));
+      const PCand bb = pbest4(wbest[par][0], wbest[par][1], wbest[par][2], wbest[par][3]);
       par ^= 1;
       if (tid == 0) SR[i] = 1;
       min_val = bb.v;
