@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
   }
   for (int i = tid; i < nr; i += 256) { u[i] = 0.0; col4row[i] = -1; }
   double vj[K], sp[K];
-  int pos[K], r4c[K];
+  int pos[K], r4c[K], pth[K];  // pth: the row that set this column's shortest-path cost (scipy's `path`), written to LDS on removal
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int j = tid + 256 * k;
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
       const int j = tid + 256 * k;
       pos[k] = j < nc ? nc - 1 - j : -1;   // remaining[it] = nc - it - 1
       sp[k] = INFINITY;
-      if (j < nc) { remaining[nc - 1 - j] = j; spc[j] = INFINITY; }
+      pth[k] = -1;
+      if (j < nc) remaining[nc - 1 - j] = j;
     }
     for (int i = tid; i < nr; i += 256) SR[i] = 0;
     __syncthreads();
@@ -455,7 +456,9 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
         if (pos[k] >= 0) {
           const int j = tid + 256 * k;
           const double r = ((min_val + (double)cv[k]) - ui) - vj[k];
-          if (r < sp[k]) { sp[k] = r; path[j] = i; spc[j] = r; }
+          const bool lower = r < sp[k];
+          sp[k] = lower ? r : sp[k];
+          pth[k] = lower ? i : pth[k];
           cand[k].v = sp[k]; cand[k].itj = (pos[k] << 16) | j; cand[k].r4 = r4c[k];
         }
       }
@@ -477,8 +480,13 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int j = tid + 256 * k;
-        if (j == bj) pos[k] = -1;                      // removed (= in SC)
-        else if (j == jl) { pos[k] = bit; remaining[bit] = jl; }
+        if (j == bj) {
+          // removed (= in SC): the only columns whose path / shortest-path cost anyone else reads (the augmentation walks the
+          // path of removed columns, the row dual update reads spc[col4row[r]] of rows in SR, whose columns are removed ones)
+          pos[k] = -1;
+          path[j] = pth[k];
+          spc[j] = sp[k];
+        } else if (j == jl) { pos[k] = bit; remaining[bit] = jl; }
       }
       n_rem -= 1;
       pbit = bit; pjl = jl;
