@@ -619,7 +619,7 @@ extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
 
 static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_RING */ 1,
-    /* AM_TUNE_RING128_MIN_TILES */ 192,
+    /* AM_TUNE_RING128_MIN_TILES */ 100,
     /* AM_TUNE_WGRAD_RING */ 1,
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,
     /* AM_TUNE_RING_SHORT_K */ 8,

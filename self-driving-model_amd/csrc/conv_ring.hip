@@ -418,7 +418,8 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   // workgroups per CU overlap one's epilogue with the other's loads, one 256x256 workgroup cannot)
   if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K)) return launch_ring<256, 256, 2, 4>(p, s);
   // 256x128 tiles run two workgroups per CU (72 KiB of LDS each); below one workgroup per CU a lone workgroup still has its CU's
-  // matrix pipes to itself, so the ring kernel keeps beating the two-stage kernels down to AM_TUNE_RING128_MIN_TILES tiles
+  // matrix pipes to itself, so the ring kernel keeps beating the two-stage kernels down to AM_TUNE_RING128_MIN_TILES tiles (100: layer4
+  // at B = 8 -- 116 tiles -- runs cfg3 2 % faster on it than on conv_gemm2_k)
   if (mt256 * ((g->N + 127) / 128) >= am_tuning(AM_TUNE_RING128_MIN_TILES)) return launch_ring<256, 128, 4, 2>(p, s);
   return AM_ERR_UNSUPPORTED;
 }
