@@ -1,7 +1,7 @@
 """A/B of the ring kernels (AM_TUNE_RING 0 / 1 / 2) on the layer shapes of the 4a step: correctness against variant 0 and
 against torch fp32 conv on the f16-rounded operands, then interleaved timing rounds in ONE process (median / min)."""
 import sys, os, ctypes
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from self_driving_model_amd.hip import conv as hc
 from self_driving_model_amd.hip import lib

@@ -618,7 +618,7 @@ thread_local int g_am_conv_variant = AM_CV_NONE;
 extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
 
 static int g_tuning[AM_TUNE_COUNT] = {
-    /* AM_TUNE_RING */ 1,
+    /* AM_TUNE_RING */ 2,
     /* AM_TUNE_RING128_MIN_TILES */ 100,
     /* AM_TUNE_WGRAD_RING */ 1,
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,

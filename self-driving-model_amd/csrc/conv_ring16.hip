@@ -7,15 +7,15 @@
 //     8-byte pieces (32 LDS writes per lane instead of 128 two-byte ones);
 //   * a K-step's two halves split by pixel sub-tile (not by k16 sub-step): the second half's pixel fragments and the next
 //     tile's weight + first-half fragments are requested one half ahead, so no read is waited for right after its issue;
-//   * SCHED picks where a wave issues the LDS-DMA pieces of the tile two K-steps ahead (each piece costs the issuing wave
-//     60-185 cycles, four pieces per wave and K-step: longer than the partner wave's 256-cycle MFMA block can cover when they
-//     sit between a wave's own two MFMA blocks):
-//       0  as a block between the two MFMA halves of an inter-barrier segment (the conv_ring_k placement);
-//       1  one piece after each of the first MFMA groups;
-//       2  by wave age -- the two waves of a SIMD (w and w + 4) share its matrix pipe and the older one wins arbitration, so
-//          between two barriers the older wave runs its 32 MFMAs first and the younger one after it: waves 0-3 issue their
-//          pieces at the END of the segment (under the younger partner's MFMAs, before the barrier wait), waves 4-7 at its
-//          START (right behind the barrier, under the older partner's MFMAs).
+//   * SCHED: 0  LDS-DMA pieces of the tile two K-steps ahead issued as a block between the two MFMA halves of an inter-barrier
+//               segment (the conv_ring_k placement);
+//            1  (default, AM_TUNE_RING = 2) the same with ONE s_setprio 1 for the second-dispatched half of the workgroup (waves
+//               4-7) before the K-loop: the two waves of a SIMD share its issue ports, the older one wins arbitration on every
+//               segment, static priority for the younger half removes its start-of-segment penalty (MI355X_MICROARCH.md, two
+//               waves per SIMD, item 4): +0.3 % / +3 % / +-0 on the layer3 / layer4 / stride-2 entry shapes;
+//            2  pieces placed by wave age -- waves 0-3 at the END of the segment (under the younger partner's MFMAs, before the
+//               barrier wait), waves 4-7 at its START (right behind the barrier): +-0.
+//     (Dropped: one piece after each of the first MFMA groups: -2 %.)
 // LDS image: rows of 64 bytes (one K-step of one pixel / one output channel), 16-byte chunk c of row r stored at position
 // c ^ swz(r) with swz = {0,2,3,1}[(r >> 2) & 3]: conflict-free for the ds_read_b128 lane groups of the 16x16x32 operand map
 // (lane l reads row l & 15, chunk l >> 4).  The LDS-DMA destination is lane-linear, so the permutation is applied to the
@@ -194,21 +194,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
 #pragma unroll
     for (int t = 0; t < HM; ++t) p1[t] = *reinterpret_cast<const half8_t*>(S + fp + (HM + t) * 16 * BKB);
     // tile kk+2 goes where tile kk-1 was: every wave finished reading it before the last barrier
-    if (SCHED == 0) issue_next();
-    if (SCHED == 1 && ikin == 0) tap_offsets(itap);
+    if (SCHED == 0 || SCHED == 1) issue_next();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
       for (int tm = 0; tm < HM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p0[tm], acc[tn][tm], 0, 0, 0);
-      if (SCHED == 1) {
-        if (tn < NLOAD) issue_piece(tn, ikk, ikin, istg);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (SCHED == 1) {
-      advance();
-      istg = istg == NSTG - 1 ? 0 : istg + 1;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (SCHED == 2 && !young) issue_next();  // older half: behind its MFMAs, under the younger partner's
@@ -233,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     __builtin_amdgcn_sched_barrier(0);
     stage = nstage;
   };
+  if (SCHED == 1 && wid >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   int kk = 0;
   for (; kk + 1 < nk; kk += 2) {
     kstep(wA, wB);
