@@ -266,6 +266,13 @@ int am_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H,
                     am_stream_t stream);
 int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int B, int IH, int IW, int C,
                         am_stream_t stream);
+/* BatchNorm (scale / shift from am_bn_finalize) + ReLU + MaxPool2d(3,2,1) of a raw conv output in one pass (the ResNet stem of a
+ * TRAINABLE expert: torchvision resnet.py conv1 -> bn1 -> relu -> maxpool): y = pool(relu(x * scale[c] + shift[c])) with the
+ * activation rounded to `dtype` before the comparison, exactly what am_bn_apply + am_maxpool3x3s2_fwd give, without writing or
+ * re-reading the normalised map.  argmax as am_maxpool3x3s2_fwd (its backward is am_maxpool3x3s2_bwd; the BatchNorm backward then
+ * takes the ReLU mask from the sign of x * scale + shift: am_bn_bwd_*_sign). */
+int am_bn_relu_maxpool3x3s2_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax,
+                                int B, int IH, int IW, int C, am_stream_t stream);
 int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
                         am_stream_t stream);
 int am_gap_nhwc_fwd(int dtype, const void* x, int ld, float* out, int B, int P, int C, am_stream_t stream);

@@ -151,14 +151,27 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const T* __restrict__ src,
 }
 
 // ---- max-pool 3x3 stride 2 pad 1, NHWC ------------------------------------------------------
+// scale / shift (am_bn_relu_maxpool3x3s2_fwd): x is a raw conv output and the pooled tensor is MaxPool(relu(x * scale + shift)), the
+// activation rounded to T before the comparison exactly as am_bn_apply would have stored it -- the normalised map (the largest
+// activation of a ResNet: 472 MB at B = 16) is neither written nor re-read
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
-                                                     int B, int IH, int IW, int OH, int OW, int C) {
+                                                     int B, int IH, int IW, int OH, int OW, int C, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift) {
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;
   const long long total = (long long)B * OH * OW * cpr;
+  const bool bn = scale != nullptr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % cpr);
+    float sc[E], sh[E];
+    if (bn) {
+#pragma unroll
+      for (int e = 0; e < E; e += 4) {
+        *reinterpret_cast<f32x4*>(sc + e) = *reinterpret_cast<const f32x4*>(scale + ch * E + e);
+        *reinterpret_cast<f32x4*>(sh + e) = *reinterpret_cast<const f32x4*>(shift + ch * E + e);
+      }
+    }
     long long t = i / cpr;
     const int ox = (int)(t % OW); t /= OW;
     const int oy = (int)(t % OH);
@@ -180,7 +193,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
         const T* v = reinterpret_cast<const T*>(&raw);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const float f = am_to_f32(v[e]);
+          float f = am_to_f32(v[e]);
+          if (bn) f = am_to_f32(am_from_f32<T>(fmaxf(f * sc[e] + sh[e], 0.f)));
           // first maximum in (kh,kw) scan order wins, NaN propagates (torch max_pool2d)
           if (first || f > best[e] || f != f) { best[e] = f; bi[e] = kh * 3 + kw; }
         }
@@ -736,8 +750,21 @@ extern "C" int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* a
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * OH * OW * (C * es / 16);
   if (total == 0) return AM_OK;
-  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C);
-  else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C);
+  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C, nullptr, nullptr);
+  else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C, nullptr, nullptr);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bn_relu_maxpool3x3s2_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax,
+                                           int B, int IH, int IW, int C, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (!DT_OK(dtype) || !x || !y || !scale || !shift || (C * es) % 16 != 0) return AM_ERR_ARG;
+  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+  const long long total = (long long)B * OH * OW * (C * es / 16);
+  if (total == 0) return AM_OK;
+  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C, scale, shift);
+  else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C, scale, shift);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

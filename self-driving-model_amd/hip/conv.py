@@ -471,6 +471,9 @@ class _Cfg:
         # its identity branch for the block's conv1 (`take`), whose input-gradient kernel adds it in its epilogue
         self.give_res_grad = False
         self.take_res_grad = False
+        # ResNet stem of a trainable trunk: conv -> BN -> ReLU -> MaxPool(3,2,1) with the normalise + ReLU + pool as ONE pass over
+        # the raw conv output (am_bn_relu_maxpool3x3s2_fwd); the call returns the POOLED activation
+        self.pool = False
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -569,15 +572,25 @@ class ConvBnAct(torch.autograd.Function):
                 _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * cout,
                        lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 2, ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(raw), None, stream()))
                 return raw  # no graph: nothing requires grad
-            y = torch.empty_like(raw)
             # (a single finalize+apply launch was measured slower: every workgroup repeats the fp64 prologue -- 1738 vs 1795 img/s)
             scale = torch.empty_like(mean)
             shift = torch.empty_like(mean)
             L.am_bn_finalize(ptr(stats), AM_STATS_REPLICAS, float(P), ptr(b) if use_batch else None, ptr(gamma), ptr(beta),
                              rmean, rvar, float(momentum), float(bn.eps), int(use_batch), ptr(scale), ptr(shift), ptr(mean),
                              ptr(rstd), cout, stream())
-            L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
-                          residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
+            pooled = cfg.pool and cfg.relu and residual is None and SIGN_RELU_MASK and ldo == cout
+            ctx.pool_arg = None
+            if pooled:
+                # normalise + ReLU + MaxPool(3,2,1) in one pass: the full-resolution activation is neither written nor re-read
+                # (backward needs the arg-max and, for the ReLU mask, only the sign of raw * scale + shift)
+                POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+                y = torch.empty((B, POH, POW, cout), dtype=dtype, device=dev)
+                ctx.pool_arg = torch.empty((B, POH, POW, cout), dtype=torch.uint8, device=dev)
+                L.am_bn_relu_maxpool3x3s2_fwd(dt_code(dtype), ptr(raw), ptr(scale), ptr(shift), ptr(y), ptr(ctx.pool_arg), B, OH, OW, cout, stream())
+            else:
+                y = torch.empty_like(raw)
+                L.am_bn_apply(dt_code(dtype), ptr(raw), ldo, ptr(scale), ptr(shift), ptr(residual),
+                              residual.shape[-1] if residual is not None else 0, int(cfg.relu), ptr(y), ldo, P, cout, stream())
             ctx.use_batch = use_batch
             # BatchNorm + ReLU without a residual: backward takes the ReLU mask from the sign of raw * scale + shift (the *_sign
             # entries) instead of reading y -- one tensor read less in each of its passes
@@ -588,7 +601,8 @@ class ConvBnAct(torch.autograd.Function):
         ctx.take_key = (x.data_ptr(), tuple(x.shape)) if cfg.take_res_grad else None
         ctx.bn_params = (gamma, beta)
         ctx.w_param = w  # the Parameter object itself (direct-mode weight gradients go into its .grad)
-        ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if (cfg.relu or bn is None) else None, mean, rstd)
+        keep_y = (cfg.relu or bn is None) and not (bn is not None and getattr(ctx, "pool_arg", None) is not None)
+        ctx.save_for_backward(x, w, b, gamma, raw if bn is not None else None, y if keep_y else None, mean, rstd)
         return y
 
     @staticmethod
@@ -598,6 +612,12 @@ class ConvBnAct(torch.autograd.Function):
         s = cfg.spec
         dtype, dev = x.dtype, x.device
         es = x.element_size()
+        if cfg.bn is not None and getattr(ctx, "pool_arg", None) is not None:
+            # the output was the pooled activation: its gradient goes back to the conv-output resolution first
+            dy = dy.contiguous()
+            full = torch.empty_like(raw)
+            L.am_maxpool3x3s2_bwd(dt_code(dtype), ptr(dy), ptr(ctx.pool_arg), ptr(full), raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3], stream())
+            dy = full
         B, OH, OW, ldo = dy.shape
         P = B * OH * OW
         cout = s.cout

@@ -33,10 +33,12 @@ class BatchNorm2d(nn.BatchNorm2d):
 
 
 def conv_bn_act(x: torch.Tensor, conv: Conv2d, bn: Optional[BatchNorm2d], relu: bool,
-                residual: Optional[torch.Tensor] = None, give_residual_grad: bool = False, take_residual_grad: bool = False) -> torch.Tensor:
-    """act(BN(conv(x)) + residual) on NHWC activations; BN mode follows bn.training.  give / take_residual_grad: see hconv._Cfg."""
+                residual: Optional[torch.Tensor] = None, give_residual_grad: bool = False, take_residual_grad: bool = False,
+                pool: bool = False) -> torch.Tensor:
+    """act(BN(conv(x)) + residual) on NHWC activations; BN mode follows bn.training.  give / take_residual_grad, pool (the call
+    returns MaxPool2d(3,2,1) of the activation when the fused pass applies -- check the output shape): see hconv._Cfg."""
     cfg = hconv._Cfg(conv.spec, conv._packed, bn, relu, runtime.loss_scale())
-    cfg.give_res_grad, cfg.take_res_grad = give_residual_grad, take_residual_grad
+    cfg.give_res_grad, cfg.take_res_grad, cfg.pool = give_residual_grad, take_residual_grad, pool
     training = bn.training if bn is not None else False
     return hconv.conv_bn_act(x, conv.weight, conv.bias, bn, relu, residual, cfg, training)
 

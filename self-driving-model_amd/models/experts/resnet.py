@@ -8,6 +8,8 @@ normalise + residual + ReLU in one elementwise pass (hip/conv.py).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -15,6 +17,9 @@ from ... import runtime
 from ...hip import conv as hconv
 from ...hip import ops as hops
 from .._nn import BatchNorm2d, Conv2d, conv_bn_act
+
+
+FUSE_STEM_POOL = os.environ.get("AUTOMOE_FUSE_STEM_POOL", "1") != "0"  # tests flip this to compare with conv -> BN -> ReLU -> separate max-pool
 
 
 class BasicBlock(nn.Module):
@@ -81,8 +86,12 @@ class Trunk(nn.Sequential):
             cfg = hconv._Cfg(self[0].spec, self[0]._packed, self[1], True, runtime.loss_scale(), getattr(x, "orig_hw", None))
             pooled = hconv.fused_stem_pool(x, self[0].weight, self[1], cfg)  # frozen stem: conv+BN+ReLU+maxpool in two light passes
         if pooled is None:
-            x = conv_bn_act(x, self[0], self[1], relu=True)
-            x = self[3](x)
+            # trainable stem: normalise + ReLU + max-pool as one pass over the raw conv output when the fused pass applies (the
+            # call then returns the pooled map); otherwise the separate pool
+            full_hw = getattr(x, "orig_hw", None)
+            y = conv_bn_act(x, self[0], self[1], relu=True, pool=FUSE_STEM_POOL)
+            conv_hw = None if full_hw is None else (hconv.out_size(full_hw[0], self[0].spec), hconv.out_size(full_hw[1], self[0].spec))
+            x = y if (conv_hw is not None and tuple(y.shape[1:3]) != conv_hw) else self[3](y)
         else:
             x = pooled
         for i in range(4, 8):

@@ -888,6 +888,41 @@ def test_nuscenes_set_loss_vs_oracle(D):
     close(bx.grad, bx_r.grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_trainable_stem_normalise_relu_maxpool_as_one_pass(dtype):
+    """Trainable ResNet stem: conv -> BN(batch statistics) -> ReLU -> MaxPool(3,2,1) with normalise + ReLU + pool as ONE pass over the
+    raw conv output (am_bn_relu_maxpool3x3s2_fwd; backward: arg-max scatter, then the BatchNorm backward with the ReLU mask from
+    the sign of the normalised output) against the three-pass sequence: the pooled activation and every gradient must agree bit
+    for bit (same roundings, same arg-max rule) up to the statistics' summation order."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import ops as hops
+    from self_driving_model_amd.models.experts import resnet
+    dev = _dev()
+    img = seeded_tensor((2, 3, 224, 320), 61)
+    probe = seeded_tensor((2, 56, 80, 64), 62).to(dev)
+    outs = {}
+    for fused in (True, False):
+        trunk = seed_module_(resnet.Trunk(), 63).to(dev).train()
+        resnet.FUSE_STEM_POOL = fused
+        try:
+            with runtime.precision(dtype, 8.0 if dtype == torch.float16 else 1.0):
+                runtime.begin_step(dev)
+                x = hops.image_to_s2d(img.to(dev), dtype)
+                from self_driving_model_amd.models._nn import conv_bn_act
+                y = conv_bn_act(x, trunk[0], trunk[1], relu=True, pool=fused)
+                if not fused:
+                    y = trunk[3](y)
+                assert tuple(y.shape) == (2, 56, 80, 64)
+                (y.float() * probe).sum().backward()
+        finally:
+            resnet.FUSE_STEM_POOL = True
+        torch.cuda.synchronize()
+        outs[fused] = (y.detach().float(), trunk[0].weight.grad.clone(), trunk[1].weight.grad.clone(), trunk[1].bias.grad.clone(),
+                       trunk[1].running_mean.clone(), trunk[1].running_var.clone())
+    for a, b in zip(outs[True], outs[False]):
+        assert rel_err(a, b) < 1e-5
+
+
 def test_eval_mode_stem_runs_conv_bn_relu_maxpool_as_one_pass():
     """Inference (eval-mode BatchNorm): the ResNet stem conv7x7/s2 -> BN(running statistics) -> ReLU -> MaxPool(3,2,1) is ONE pass
     over the space-to-depth image (am_conv_first_fused mode 3 with scale / shift from the running statistics) instead of conv
