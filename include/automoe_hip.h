@@ -275,6 +275,14 @@ int am_bn_relu_maxpool3x3s2_fwd(int dtype, const void* x, const float* scale, co
                                 int B, int IH, int IW, int C, am_stream_t stream);
 int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
                         am_stream_t stream);
+/* am_maxpool3x3s2_bwd for a pooled conv -> BatchNorm -> ReLU layer (the ResNet stem), fused with that BatchNorm's backward reduce pass:
+ * while a pixel's gradient is in registers the kernel reads the raw conv output there and accumulates `sums` (the layout
+ * am_bn_bwd_reduce fills, zeroed by the caller; ReLU mask = sign of raw * scale + shift as am_bn_bwd_reduce_sign), so that pass over
+ * the two full-resolution tensors is not run.  AM_ERR_UNSUPPORTED when the channel count does not give every thread a fixed
+ * 16-byte channel chunk (caller: am_maxpool3x3s2_bwd + am_bn_bwd_reduce_sign). */
+int am_maxpool3x3s2_bwd_bn(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
+                           const void* raw, const float* mean, const float* rstd, const float* scale, const float* shift,
+                           double* sums, am_stream_t stream);
 int am_gap_nhwc_fwd(int dtype, const void* x, int ld, float* out, int B, int P, int C, am_stream_t stream);
 int am_gap_nhwc_bwd(int dtype, const float* dout, void* dx, int ld, int B, int P, int C, float mul,
                     am_stream_t stream);

@@ -220,13 +220,30 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
 // kw = px + 1 - 2wx (valid when 0 <= kh, kw <= 2: an even row / column belongs to one window only).  Four dY loads, four
 // arg-max loads, four stores per thread, no data-dependent control flow: 422 -> ~2x faster than one pixel per thread on the stem
 // map ([16,360,640,64]: 650 MB of algorithmic traffic).  Contributions are summed in the order of the per-pixel form.
-template <typename T>
+// BNR (am_maxpool3x3s2_bwd_bn): the pooled layer is conv -> BatchNorm -> ReLU (the ResNet stem); while the gradient of a pixel is in
+// registers the kernel also reads the raw conv output there and accumulates the BatchNorm-backward sums (sum dz, sum dz * xhat with
+// dz = dx masked by the sign of raw * scale + shift: bn.hip bn_bwd_reduce_k's arithmetic on the ROUNDED gradient it would have
+// read), so the separate reduce pass over the two full-resolution tensors is not run.  Needs 256 % (C / E) == 0: a thread keeps its
+// channel chunk.
+template <typename T, bool BNR>
 __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
-                                                           int B, int IH, int IW, int OH, int OW, int C) {
+                                                           int B, int IH, int IW, int OH, int OW, int C, const T* __restrict__ raw,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ sg_scale, const float* __restrict__ sg_shift,
+                                                           double* __restrict__ sums) {
   constexpr int E = 16 / (int)sizeof(T);
   const int cpr = C / E;
   const int BH = (IH + 1) / 2, BW = (IW + 1) / 2;
   const long long total = (long long)B * BH * BW * cpr;
+  float bs[E], bq[E], mu[E], rs[E], ssc[E], ssh[E];
+  if (BNR) {
+    const int c0 = (int)(threadIdx.x % cpr) * E;  // == (i % cpr) * E for every i of this thread (grid stride is a multiple of 256)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      bs[e] = bq[e] = 0.f;
+      mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; ssc[e] = sg_scale[c0 + e]; ssh[e] = sg_shift[c0 + e];
+    }
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % cpr);
     long long t = i / cpr;
@@ -282,8 +299,36 @@ __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__
         T* o = reinterpret_cast<T*>(&outraw);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(acc[e]);
-        *reinterpret_cast<uint4*>(dx + (((long long)b * IH + iy) * IW + ix) * C + ch * E) = outraw;
+        const long long xoff = (((long long)b * IH + iy) * IW + ix) * C + ch * E;
+        *reinterpret_cast<uint4*>(dx + xoff) = outraw;
+        if (BNR) {
+          const uint4 rraw = *reinterpret_cast<const uint4*>(raw + xoff);
+          const T* rv = reinterpret_cast<const T*>(&rraw);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float xf = am_to_f32(rv[e]);
+            float dz = am_to_f32(o[e]);
+            if (!(xf * ssc[e] + ssh[e] > 0.f)) dz = 0.f;
+            bs[e] += dz;
+            bq[e] += dz * (xf - mu[e]) * rs[e];
+          }
+        }
       }
+    }
+  }
+  if (BNR) {
+    // block reduction over the threads that share a channel chunk, then fp64 atomics into the replicas (as bn_bwd_reduce_k)
+    extern __shared__ float red[];  // [256][2E]
+    const int tid = threadIdx.x, rpp = 256 / cpr;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { red[tid * 2 * E + e] = bs[e]; red[tid * 2 * E + E + e] = bq[e]; }
+    __syncthreads();
+    for (int o = tid; o < cpr * E * 2; o += 256) {
+      const int which = o / (cpr * E), ce = o % (cpr * E);
+      const int chn = ce / E, e = ce % E;
+      double a = 0.0;
+      for (int r = 0; r < rpp; ++r) a += (double)red[(r * cpr + chn) * 2 * E + which * E + e];
+      atomicAdd(sums + (size_t)(blockIdx.x % AM_STATS_REPLICAS) * 2 * C + (size_t)which * C + ce, a);
     }
   }
 }
@@ -776,8 +821,25 @@ extern "C" int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* arg
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * (C * es / 16);
   if (total == 0) return AM_OK;
-  if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_bwd_block_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C);
-  else hipLaunchKernelGGL(maxpool_bwd_block_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C);
+  if (dtype == AM_F16) hipLaunchKernelGGL((maxpool_bwd_block_k<half_t, false>), dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((maxpool_bwd_block_k<float, false>), dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_maxpool3x3s2_bwd_bn(int dtype, const void* dy, const uint8_t* argmax, void* dx, int B, int IH, int IW, int C,
+                                      const void* raw, const float* mean, const float* rstd, const float* scale, const float* shift,
+                                      double* sums, am_stream_t stream) {
+  const int es = dtype == AM_F16 ? 2 : 4;
+  if (!DT_OK(dtype) || !dy || !dx || !argmax || !raw || !mean || !rstd || !scale || !shift || !sums || (C * es) % 16 != 0) return AM_ERR_ARG;
+  const int cpr = C * es / 16;
+  if (cpr > 256 || 256 % cpr != 0) return AM_ERR_UNSUPPORTED;  // caller: am_maxpool3x3s2_bwd + am_bn_bwd_reduce_sign
+  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+  const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * cpr;
+  if (total == 0) return AM_OK;
+  const size_t lds = 256 * 2 * (16 / es) * sizeof(float);
+  if (dtype == AM_F16) hipLaunchKernelGGL((maxpool_bwd_block_k<half_t, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C, (const half_t*)raw, mean, rstd, scale, shift, sums);
+  else hipLaunchKernelGGL((maxpool_bwd_block_k<float, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C, (const float*)raw, mean, rstd, scale, shift, sums);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -612,11 +612,21 @@ class ConvBnAct(torch.autograd.Function):
         s = cfg.spec
         dtype, dev = x.dtype, x.device
         es = x.element_size()
+        pool_sums = None
         if cfg.bn is not None and getattr(ctx, "pool_arg", None) is not None:
-            # the output was the pooled activation: its gradient goes back to the conv-output resolution first
+            # the output was the pooled activation: its gradient goes back to the conv-output resolution first -- and the same pass
+            # accumulates the BatchNorm-backward sums (am_maxpool3x3s2_bwd_bn), so the reduce pass below is skipped
             dy = dy.contiguous()
             full = torch.empty_like(raw)
-            L.am_maxpool3x3s2_bwd(dt_code(dtype), ptr(dy), ptr(ctx.pool_arg), ptr(full), raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3], stream())
+            pool_sums = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * s.cout, dev)
+            try:
+                L.am_maxpool3x3s2_bwd_bn(dt_code(dtype), ptr(dy), ptr(ctx.pool_arg), ptr(full), raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3],
+                                         ptr(raw), ptr(mean), ptr(rstd), ptr(ctx.sign_ss[0]), ptr(ctx.sign_ss[1]), ptr(pool_sums), stream())
+            except RuntimeError as e:
+                if "UNSUPPORTED" not in str(e):
+                    raise
+                pool_sums = None
+                L.am_maxpool3x3s2_bwd(dt_code(dtype), ptr(dy), ptr(ctx.pool_arg), ptr(full), raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3], stream())
             dy = full
         B, OH, OW, ldo = dy.shape
         P = B * OH * OW
@@ -626,9 +636,11 @@ class ConvBnAct(torch.autograd.Function):
         code = dt_code(dtype)
         db = dgamma = dbeta = dres = None
         if cfg.bn is not None:
-            sums = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev)
+            sums = pool_sums if pool_sums is not None else _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * cout, dev)
             sign_ss = ctx.sign_ss
-            if sign_ss is not None:
+            if pool_sums is not None:
+                pass  # filled by am_maxpool3x3s2_bwd_bn above
+            elif sign_ss is not None:
                 L.am_bn_bwd_reduce_sign(code, ptr(dy), ldo, ptr(raw), ldo, ptr(mean), ptr(rstd), ptr(sign_ss[0]), ptr(sign_ss[1]), ptr(sums), P,
                                         cout, stream())
             else:
