@@ -100,7 +100,9 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
   const half_t* __restrict__ yout = static_cast<const half_t*>(p.yout);
 
   uint4 rp[PCH], rd[DCH], rx[BNF ? DCH : 1], ry[BNF ? DCH : 1];
+  unsigned inside = 0;  // bit k: chunk k of the loaded tile lies inside the output image (outside: dY stays zero, no transform)
   auto load_tile = [&](int tile) {
+    inside = 0;
     const int img = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - img * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
       const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
       uint4 v = make_uint4(0u, 0u, 0u, 0u), xr = v, yr = v;
       if (oy < p.OH && ox < p.OW && cc * 8 < p.ldo - p.y_coff) {
+        inside |= 1u << k;
         const long long off = ((long long)(img * p.OH + oy) * p.OW + ox) * p.ldo + p.y_coff + cc * 8;
         v = *reinterpret_cast<const uint4*>(dy + off);
         if constexpr (BNF) {
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
       const int c = tid + k * NTH;
       const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
       uint4 v = rd[k];
-      if constexpr (BNF) v = bn_transform(v, rx[k], ry[k], cc);
+      if constexpr (BNF) {
+        if (inside & (1u << k)) v = bn_transform(v, rx[k], ry[k], cc);  // (a pixel outside the image has no gradient: the affine part of the
+      }                                                                 // BatchNorm backward would otherwise leave -c0 * (c1 + xhat * c2) there)
       *reinterpret_cast<uint4*>(dYs + pix * PDY + cc * 16) = v;
     }
   };

@@ -724,6 +724,53 @@ def test_first_layer_weight_gradient_kernels_vs_torch(spec):
     assert rel_err(dw, ref) < 2e-3, rel_err(dw, ref)
 
 
+@pytest.mark.parametrize("spec", [(64, 7, 3), (32, 5, 2)])
+def test_first_layer_fused_bn_weight_gradient_equals_the_two_pass_sequence(spec):
+    """am_conv_wgrad_bn / _sign (BatchNorm backward formed in the weight-gradient kernel's tile load) against am_bn_bwd_apply[_sign]
+    followed by am_conv_wgrad on the tensor it writes, on an output size with ragged tiles in both directions: the same rounded
+    values enter the same MFMAs, so the two agree to the order of the fp32 atomics (a tile pixel outside the image must contribute
+    nothing: the affine part of the BatchNorm backward is not zero there)."""
+    import ctypes
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    cout, k, pad = spec
+    B, H, W = 2, 150, 214  # conv output 75 x 107
+    g = torch.Generator().manual_seed(20 + k)
+    L = hc._L()
+    s = hc.ConvSpec(3, cout, k, 2, pad, first=True)
+    with runtime.precision(torch.float16, 1.0):
+        x = hops.image_to_s2d(torch.randn(B, 3, H, W, generator=g).to(_dev()), torch.float16)
+    geo = hc.fwd_geom(s, B, x.shape[1], x.shape[2], 16, hc.channel_ld(cout, 2), 2, orig_hw=(H, W))
+    OH, OW, ld = geo.OH, geo.OW, geo.ldo
+    P = B * OH * OW
+    dy = torch.zeros(B, OH, OW, ld, dtype=torch.float16); dy[..., :cout] = torch.randn(B, OH, OW, cout, generator=g).half()
+    raw = torch.zeros(B, OH, OW, ld, dtype=torch.float16); raw[..., :cout] = torch.randn(B, OH, OW, cout, generator=g).half()
+    dy, raw = dy.to(_dev()), raw.to(_dev())
+    mean, rstd = (0.1 * torch.randn(cout, generator=g)).to(_dev()), (0.5 + torch.rand(cout, generator=g)).to(_dev())
+    coef = torch.cat([0.5 + torch.rand(cout, generator=g), 0.05 * torch.randn(cout, generator=g), 0.05 * torch.randn(cout, generator=g)]).to(_dev())
+    scale, shift = (0.5 + torch.rand(cout, generator=g)).to(_dev()), (0.2 * torch.randn(cout, generator=g)).to(_dev())
+    y = torch.relu(raw.float() * torch.nn.functional.pad(scale, (0, ld - cout)) + torch.nn.functional.pad(shift, (0, ld - cout))).half()
+    code, p, st = hc.dt_code(torch.float16), hc.ptr, hc.stream()
+    ktot = geo.ntaps * geo.krun
+    for sign in (True, False):
+        dz = torch.zeros_like(dy)
+        if sign:
+            L.am_bn_bwd_apply_sign(code, p(dy), ld, p(raw), ld, p(mean), p(rstd), p(coef), p(scale), p(shift), p(dz), ld, P, cout, st)
+        else:
+            L.am_bn_bwd_apply(code, p(dy), ld, p(y), ld, p(raw), ld, p(mean), p(rstd), p(coef), 1, p(dz), ld, None, 0, P, cout, st)
+        two_pass = torch.zeros(cout, ktot, device=_dev())
+        hc.conv_wgrad(geo, x, dz, 1.0, two_pass)
+        fused = torch.zeros(cout, ktot, device=_dev())
+        if sign:
+            L.am_conv_wgrad_bn_sign(ctypes.byref(geo), code, p(x), p(dy), p(raw), p(mean), p(rstd), p(coef), p(scale), p(shift), 1.0, p(fused), st)
+        else:
+            L.am_conv_wgrad_bn(ctypes.byref(geo), code, p(x), p(dy), p(y), p(raw), p(mean), p(rstd), p(coef), 1, 1.0, p(fused), st)
+        launched_kernel("conv_s2d_wgrad_k", what=f"fused first-layer wgrad {spec}")
+        torch.cuda.synchronize()
+        assert rel_err(fused, two_pass) < 1e-5, (sign, rel_err(fused, two_pass))
+
+
 S2_DGRAD_KERNEL = {((128, 256, 4, 240, 256), True): "conv_ring16_k<256,256>", ((128, 256, 4, 240, 256), False): "conv_ring16_k<256,256>",
                    ((64, 128, 2, 320, 320), True): "conv_ring_k<256,128>", ((64, 128, 2, 320, 320), False): "conv_ring_k<256,128>",
                    ((32, 64, 2, 256, 256), True): "conv_gemm2_k", ((32, 64, 2, 256, 256), False): "conv_gemm2_k"}
