@@ -516,6 +516,11 @@ def test_conv_halo_kernel_vs_torch_and_ring_kernel(case):
                 try:
                     L.am_conv_gemm_res(ctypes.byref(geom), hc.dt_code(torch.float16), hc.ptr(xd), hc.ptr(wp), hc.ptr(b.to(_dev())),
                                        hc.ptr(nhwc(r, torch.float16)), 1, hc.ptr(y3), hc.stream())
+                    # bit for bit the two-pass sequence on the same kernel: conv + bias rounded to f16, then + residual, ReLU, rounded
+                    y1 = torch.zeros_like(y)
+                    hc.conv_gemm(geom, xd, wp, b.to(_dev()), False, y1, None)
+                    torch.cuda.synchronize()
+                    assert torch.equal(y3, torch.relu(y1.float() + nhwc(r, torch.float16).float()).half()), "residual epilogue differs from the two-pass sequence"
                 except RuntimeError as e:  # the gather kernels decline small grids: only the halo run is checked then
                     assert "UNSUPPORTED" in str(e) and kernel is None
                     y3 = None
