@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
   const long long total = (long long)B * OH * OW * cpr;
   const bool bn = scale != nullptr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cpr);
+    // (32-bit index arithmetic: the launcher checks total < 2^31; four 64-bit divisions per iteration cost more than the pooling)
+    const unsigned iu = (unsigned)i;
+    const int ch = (int)(iu % (unsigned)cpr);
     float sc[E], sh[E];
     if (bn) {
 #pragma unroll
@@ -172,34 +174,43 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
         *reinterpret_cast<f32x4*>(sh + e) = *reinterpret_cast<const f32x4*>(shift + ch * E + e);
       }
     }
-    long long t = i / cpr;
-    const int ox = (int)(t % OW); t /= OW;
-    const int oy = (int)(t % OH);
-    const int b = (int)(t / OH);
+    unsigned t = iu / (unsigned)cpr;
+    const int ox = (int)(t % (unsigned)OW); t /= (unsigned)OW;
+    const int oy = (int)(t % (unsigned)OH);
+    const int b = (int)(t / (unsigned)OH);
     float best[E];
     int bi[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { best[e] = -INFINITY; bi[e] = 0; }
-    bool first = true;
+    // all nine window loads first, at clamped (always valid) addresses, then the comparisons: with the bounds tests as branches
+    // around each load the taps ran one memory round trip after the other (3.0 TB/s on the stem map)
+    uint4 win[9];
+    bool ok[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int iy = oy * 2 - 1 + kh;
-      if ((unsigned)iy >= (unsigned)IH) continue;
+      const int iyc = min(max(iy, 0), IH - 1);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ix = ox * 2 - 1 + kw;
-        if ((unsigned)ix >= (unsigned)IW) continue;
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + (((long long)b * IH + iy) * IW + ix) * C + ch * E);
-        const T* v = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          float f = am_to_f32(v[e]);
-          if (bn) f = am_to_f32(am_from_f32<T>(fmaxf(f * sc[e] + sh[e], 0.f)));
-          // first maximum in (kh,kw) scan order wins, NaN propagates (torch max_pool2d)
-          if (first || f > best[e] || f != f) { best[e] = f; bi[e] = kh * 3 + kw; }
-        }
-        first = false;
+        const int ixc = min(max(ix, 0), IW - 1);
+        ok[kh * 3 + kw] = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        win[kh * 3 + kw] = *reinterpret_cast<const uint4*>(x + (((long long)b * IH + iyc) * IW + ixc) * C + ch * E);
       }
+    }
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (!ok[k]) continue;
+      const T* v = reinterpret_cast<const T*>(&win[k]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float f = am_to_f32(v[e]);
+        if (bn) f = am_to_f32(am_from_f32<T>(fmaxf(f * sc[e] + sh[e], 0.f)));
+        // first maximum in (kh,kw) scan order wins, NaN propagates (torch max_pool2d)
+        if (first || f > best[e] || f != f) { best[e] = f; bi[e] = k; }
+      }
+      first = false;
     }
     uint4 outraw;
     T* o = reinterpret_cast<T*>(&outraw);
@@ -207,9 +218,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, T*
     for (int e = 0; e < E; ++e) o[e] = am_from_f32<T>(best[e]);
     const long long ooff = (((long long)b * OH + oy) * OW + ox) * C + ch * E;
     *reinterpret_cast<uint4*>(y + ooff) = outraw;
-    if (arg) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) arg[ooff + e] = (uint8_t)bi[e];
+    if (arg) {  // the E codes of this chunk as ONE store (eight byte stores per thread were the kernel's bottleneck: 1.8 TB/s)
+      if constexpr (E == 8) {
+        uint2 packed;
+        packed.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+        packed.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+        *reinterpret_cast<uint2*>(arg + ooff) = packed;
+      } else {
+        *reinterpret_cast<unsigned*>(arg + ooff) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+      }
     }
   }
 }
@@ -245,11 +262,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__
     }
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cpr);
-    long long t = i / cpr;
-    const int X = (int)(t % BW); t /= BW;
-    const int Y = (int)(t % BH);
-    const int b = (int)(t / BH);
+    const unsigned iu = (unsigned)i;  // (32-bit index arithmetic: the launcher checks total < 2^31)
+    const int ch = (int)(iu % (unsigned)cpr);
+    unsigned t = iu / (unsigned)cpr;
+    const int X = (int)(t % (unsigned)BW); t /= (unsigned)BW;
+    const int Y = (int)(t % (unsigned)BH);
+    const int b = (int)(t / (unsigned)BH);
     float g[2][2][E];
     uint8_t a[2][2][E];
 #pragma unroll
@@ -795,6 +813,7 @@ extern "C" int am_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* a
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * OH * OW * (C * es / 16);
   if (total == 0) return AM_OK;
+  if (total >= (1ll << 31)) return AM_ERR_UNSUPPORTED;  // 32-bit index arithmetic in the kernel
   if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C, nullptr, nullptr);
   else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C, nullptr, nullptr);
   AM_CHECK_LAUNCH();
@@ -808,6 +827,7 @@ extern "C" int am_bn_relu_maxpool3x3s2_fwd(int dtype, const void* x, const float
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * OH * OW * (C * es / 16);
   if (total == 0) return AM_OK;
+  if (total >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
   if (dtype == AM_F16) hipLaunchKernelGGL(maxpool_fwd_k<half_t>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)x, (half_t*)y, argmax, B, IH, IW, OH, OW, C, scale, shift);
   else hipLaunchKernelGGL(maxpool_fwd_k<float>, dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, B, IH, IW, OH, OW, C, scale, shift);
   AM_CHECK_LAUNCH();
@@ -821,6 +841,7 @@ extern "C" int am_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* arg
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * (C * es / 16);
   if (total == 0) return AM_OK;
+  if (total >= (1ll << 31)) return AM_ERR_UNSUPPORTED;  // 32-bit index arithmetic in the kernel
   if (dtype == AM_F16) hipLaunchKernelGGL((maxpool_bwd_block_k<half_t, false>), dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   else hipLaunchKernelGGL((maxpool_bwd_block_k<float, false>), dim3(ew_grid(total)), dim3(256), 0, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   AM_CHECK_LAUNCH();
@@ -837,6 +858,7 @@ extern "C" int am_maxpool3x3s2_bwd_bn(int dtype, const void* dy, const uint8_t* 
   const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
   const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * cpr;
   if (total == 0) return AM_OK;
+  if (total >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
   const size_t lds = 256 * 2 * (16 / es) * sizeof(float);
   if (dtype == AM_F16) hipLaunchKernelGGL((maxpool_bwd_block_k<half_t, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C, (const half_t*)raw, mean, rstd, scale, shift, sums);
   else hipLaunchKernelGGL((maxpool_bwd_block_k<float, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C, (const float*)raw, mean, rstd, scale, shift, sums);
