@@ -681,7 +681,10 @@ __global__ __launch_bounds__(256) void upsample_ce2d_k(const T* __restrict__ low
         rp[c] = hx * r0[2 * ncell * C + c] + lx * r1[2 * ncell * C + c];
       }
       const long long* tcol = target + (long long)b * H * W + X;
+      long long t_next = tcol[(long long)Ylo * W];  // labels one row ahead: the load is in flight under the previous row's softmax
       for (int Y = Ylo; Y <= Yhi; ++Y) {
+        const long long t = t_next;
+        t_next = tcol[(long long)min(Y + 1, Yhi) * W];
         int y0, y1;
         float ly;
         src_index(Y, sh, h, y0, y1, ly);
@@ -689,7 +692,6 @@ __global__ __launch_bounds__(256) void upsample_ce2d_k(const T* __restrict__ low
         if (y0 == y) wy += 1.f - ly;
         if (y1 == y) wy += ly;
         if (wy == 0.f) continue;
-        const long long t = tcol[(long long)Y * W];
         if (t == ignore_index) continue;
         const float hy = 1.f - ly;
         const bool top_c = y0 == y, bot_c = y1 == y;
