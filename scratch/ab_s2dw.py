@@ -5,13 +5,14 @@ import torch
 from self_driving_model_amd.hip import conv as hc, lib
 L = lib.get()
 B = int(os.environ.get("B", 16)); dt = torch.float16; dev = torch.device("cuda:0")
-s = hc.ConvSpec(3, 64, 7, 2, 3, first=True); IH, IW = 720, 1280
+COUT, K, PAD = (32, 5, 2) if os.environ.get("POLICY") else (64, 7, 3)
+s = hc.ConvSpec(3, COUT, K, 2, PAD, first=True); IH, IW = 720, 1280
 OH, OW = hc.out_size(IH, s), hc.out_size(IW, s)
 x = torch.randn(B, IH // 2, IW // 2, 16, device=dev).to(dt)
 g = hc.fwd_geom(s, B, IH // 2, IW // 2, 16, s.cout, 2, orig_hw=(IH, IW))
-dy = torch.randn(B, OH, OW, 64, device=dev).to(dt); raw = torch.randn_like(dy); y = torch.relu(raw)
-mean = torch.zeros(64, device=dev); rstd = torch.ones(64, device=dev); coef = torch.rand(3 * 64, device=dev)
-dwp = torch.zeros(64, g.ntaps * g.krun, dtype=torch.float32, device=dev)
+dy = torch.randn(B, OH, OW, COUT, device=dev).to(dt); raw = torch.randn_like(dy); y = torch.relu(raw)
+mean = torch.zeros(COUT, device=dev); rstd = torch.ones(COUT, device=dev); coef = torch.rand(3 * COUT, device=dev)
+dwp = torch.zeros(COUT, g.ntaps * g.krun, dtype=torch.float32, device=dev)
 def t(f, n=10):
     for _ in range(3): f()
     torch.cuda.synchronize()
