@@ -203,3 +203,111 @@ def test_lsap_random_sizes_against_scipy(seed):
             k = int(count[b_])
             assert int(status[b_]) == 0 and k == len(r_ref)
             assert np.array_equal(rows[b_, :k].cpu().numpy(), r_ref) and np.array_equal(cols[b_, :k].cpu().numpy(), c_ref), (seed, transposed, b_)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_layer1_epilogue_kernel_on_random_shapes(seed):
+    """conv3x3_c64n64_duo_k's inference form (bias / ReLU / residual epilogue) on random map sizes with ragged 8x16 tiles: against
+    torch, and the residual form bit for bit against conv + bias (rounded) -> + residual -> ReLU (rounded)."""
+    from self_driving_model_amd.hip import conv as hc
+    L = hc._L()
+    rng = np.random.default_rng(500 + seed)
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(150, 260)), int(rng.integers(160, 330))
+    if B * H * W < 65536:
+        B += 1
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 64, H, W, generator=g).half().float()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
+    b = torch.randn(64, generator=g)
+    r = torch.randn(B, 64, H, W, generator=g).half().float()
+    s = hc.ConvSpec(64, 64, 3, 1, 1)
+    geom = hc.fwd_geom(s, B, H, W, 64, 64, 2)
+    xd, wp, bd, rd = _nhwc(x), hc.pack_fwd(w.to(_dev()), s, torch.float16), b.to(_dev()), _nhwc(r)
+    code, p, st = hc.dt_code(torch.float16), hc.ptr, hc.stream()
+    y_b = torch.zeros(B, H, W, 64, dtype=torch.float16, device=_dev())
+    hc.conv_gemm(geom, xd, wp, bd, False, y_b, None)
+    assert L.am_conv_last_variant() == 3
+    y_br = torch.zeros_like(y_b)
+    hc.conv_gemm(geom, xd, wp, bd, True, y_br, None)
+    y_r = torch.zeros_like(y_b)
+    L.am_conv_gemm_res(ctypes.byref(geom), code, p(xd), p(wp), p(bd), p(rd), 1, p(y_r), st)
+    assert L.am_conv_last_variant() == 3
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_err(y_b.permute(0, 3, 1, 2), ref) < 1e-3
+    assert torch.equal(y_br, torch.relu(y_b.float()).half())
+    assert torch.equal(y_r, torch.relu(y_b.float() + rd.float()).half())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_first_layer_fused_weight_gradient_on_random_image_sizes(seed):
+    """conv_s2d_wgrad_k's fused BatchNorm-backward form against am_bn_bwd_apply_sign + the plain form, for the stem (7x7, 64) and the
+    policy first layer (5x5, 32), on random image sizes (ragged 8x32 tiles, odd output sizes)."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import ops as hops
+    L = hc._L()
+    rng = np.random.default_rng(600 + seed)
+    cout, k, pad = (64, 7, 3) if seed % 2 == 0 else (32, 5, 2)
+    B, H, W = int(rng.integers(1, 3)), 2 * int(rng.integers(50, 120)), 2 * int(rng.integers(60, 150))
+    g = torch.Generator().manual_seed(seed)
+    s = hc.ConvSpec(3, cout, k, 2, pad, first=True)
+    with runtime.precision(torch.float16, 1.0):
+        x = hops.image_to_s2d(torch.randn(B, 3, H, W, generator=g).to(_dev()), torch.float16)
+    geo = hc.fwd_geom(s, B, x.shape[1], x.shape[2], 16, hc.channel_ld(cout, 2), 2, orig_hw=(H, W))
+    OH, OW, ld = geo.OH, geo.OW, geo.ldo
+    if B * OH * OW < 2048:
+        pytest.skip("below the patch kernel's size gate")
+    P = B * OH * OW
+    dy = torch.zeros(B, OH, OW, ld, dtype=torch.float16); dy[..., :cout] = torch.randn(B, OH, OW, cout, generator=g).half()
+    raw = torch.zeros(B, OH, OW, ld, dtype=torch.float16); raw[..., :cout] = torch.randn(B, OH, OW, cout, generator=g).half()
+    dy, raw = dy.to(_dev()), raw.to(_dev())
+    mean, rstd = (0.1 * torch.randn(cout, generator=g)).to(_dev()), (0.5 + torch.rand(cout, generator=g)).to(_dev())
+    coef = torch.cat([0.5 + torch.rand(cout, generator=g), 0.05 * torch.randn(cout, generator=g), 0.05 * torch.randn(cout, generator=g)]).to(_dev())
+    scale, shift = (0.5 + torch.rand(cout, generator=g)).to(_dev()), (0.2 * torch.randn(cout, generator=g)).to(_dev())
+    code, p, st = hc.dt_code(torch.float16), hc.ptr, hc.stream()
+    ktot = geo.ntaps * geo.krun
+    dz = torch.zeros_like(dy)
+    L.am_bn_bwd_apply_sign(code, p(dy), ld, p(raw), ld, p(mean), p(rstd), p(coef), p(scale), p(shift), p(dz), ld, P, cout, st)
+    two_pass = torch.zeros(cout, ktot, device=_dev())
+    hc.conv_wgrad(geo, x, dz, 1.0, two_pass)
+    assert L.am_conv_last_variant() == 15
+    fused = torch.zeros(cout, ktot, device=_dev())
+    L.am_conv_wgrad_bn_sign(ctypes.byref(geo), code, p(x), p(dy), p(raw), p(mean), p(rstd), p(coef), p(scale), p(shift), 1.0, p(fused), st)
+    torch.cuda.synchronize()
+    assert rel_err(fused, two_pass) < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fused_dense_loss_on_random_sizes(seed):
+    """am_upsample_ce2d_* against BilinearUp -> CrossEntropy2d on random low / high resolutions (non-integer scales, maps narrower
+    than one column group, one-row maps), both class counts and dtypes."""
+    from self_driving_model_amd.hip import ops as hops
+    rng = np.random.default_rng(700 + seed)
+    C = 3 if seed % 2 else 19
+    dtype = torch.float16 if seed < 2 else torch.float32
+    B, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 20))
+    H, W = int(h * rng.uniform(1.5, 20)), int(w * rng.uniform(1.5, 20))
+    ld = C if (C * (2 if dtype == torch.float16 else 4)) % 16 == 0 else 32
+    g = torch.Generator().manual_seed(seed)
+    low = (torch.randn(B, h, w, C, generator=g) * 2).to(dtype)
+    tgt = torch.randint(0, C, (B, H, W), generator=g)
+    tgt[torch.rand(B, H, W, generator=g) < 0.2] = 255
+    ls = 16.0 if dtype == torch.float16 else 1.0
+
+    def run(fused):
+        lowd = torch.zeros(B, h, w, ld, dtype=dtype, device=_dev())
+        lowd[..., :C] = low.to(_dev())
+        lowd.requires_grad_()
+        if fused:
+            loss = hops.UpsampleCrossEntropy.apply(lowd, tgt.to(_dev()), C, H, W, 255, ls)
+        else:
+            loss = hops.CrossEntropy2d.apply(hops.BilinearUp.apply(lowd, C, H, W, ls), tgt.to(_dev()), 255)
+        (loss * 0.7).backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), lowd.grad.float()
+
+    lf, gf = run(True)
+    lu, gu = run(False)
+    assert abs(lf - lu) <= 1e-5 * max(1.0, abs(lu))
+    assert rel_err(gf, gu) < (2e-3 if dtype == torch.float16 else 1e-5), (B, h, w, H, W, C)
