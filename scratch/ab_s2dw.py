@@ -23,4 +23,8 @@ def t(f, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 plain = lambda: L.am_conv_wgrad(ctypes.byref(g), hc.dt_code(dt), hc.ptr(x), hc.ptr(dy), 1.0, hc.ptr(dwp), hc.stream())
 bnf = lambda: L.am_conv_wgrad_bn(ctypes.byref(g), hc.dt_code(dt), hc.ptr(x), hc.ptr(dy), hc.ptr(y), hc.ptr(raw), hc.ptr(mean), hc.ptr(rstd), hc.ptr(coef), 1, 1.0, hc.ptr(dwp), hc.stream())
+sc, sh = torch.rand(COUT, device=dev) + 0.5, torch.randn(COUT, device=dev)
+sg = lambda: L.am_conv_wgrad_bn_sign(ctypes.byref(g), hc.dt_code(dt), hc.ptr(x), hc.ptr(dy), hc.ptr(raw), hc.ptr(mean), hc.ptr(rstd), hc.ptr(coef), hc.ptr(sc), hc.ptr(sh), 1.0, hc.ptr(dwp), hc.stream())
+for _ in range(3):
+    print(f"B={B}  sign {t(sg):7.1f} us   fused-BN(y) {t(bnf):7.1f} us", flush=True)
 print(f"B={B}  plain {t(plain):7.1f} us   fused-BN {t(bnf):7.1f} us", flush=True)

@@ -9,6 +9,7 @@ typedef _Float16 half_t;
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));

@@ -12,6 +12,8 @@
 // in the fused-BatchNorm form, the conv output and the ReLU mask, 14 x 16 B per thread -- are issued before the MFMA phase and
 // consumed after it (the BatchNorm-backward transform runs when the tile is stored to LDS), so ~115 KB per CU are in flight
 // under the MFMAs.  (Four waves with the transform at load time ran the fused form at 2.5 TB/s: 688 us for the stem at B = 16.)
+// The transform's per-channel constants sit in registers as pairs for the packed fp32 instructions and the mask mode is a template
+// parameter (read from LDS per element they made the transform LDS- and VALU-bound: stem at B = 16 448 -> 288 us, 3.7 TB/s).
 #include "am_common.h"
 
 namespace amw {
@@ -49,9 +51,10 @@ __device__ __forceinline__ half8_t tr_frag(const char* lo_addr, int hi_delta) {
 
 // NT = number of 32-channel blocks of dY (1: N <= 32, 2: N <= 64).  Wave w of 8: NT == 1 -> tile row w; NT == 2 ->
 // channel block w & 1, then tap group, then row group (see TSP below).
-template <int TAPS, int NT, bool BNF>
+// BNF: 0 plain, 1 fused BatchNorm backward with the ReLU mask read from yout (or no ReLU), 2 the same with the sign mask
+template <int TAPS, int NT, int BNF>
 __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) {
-  constexpr int NTH = 512;
+  constexpr int NW = 8, NTH = NW * 64;  // (two workgroups of four waves per CU: the fused forms spill, the plain form gains nothing)
   constexpr int PH = TH + TAPS - 1;
   constexpr int PATCH_PIX = PH * PW;
   constexpr int PATCH_BYTES = PATCH_PIX * PPITCH;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
   // costs an s_waitcnt vmcnt(0), i.e. the whole prefetch)
   constexpr int TSP = (NT == 2 && TAPS % 2 == 0) ? 2 : 1;
   constexpr int TPW = TAPS / TSP;                       // taps (patch rows) per wave
-  constexpr int ROWS = TH / (8 / (NT * TSP));           // tile rows per wave
+  constexpr int ROWS = TH / (NW / (NT * TSP));           // tile rows per wave
   constexpr int KTOT = TAPS * 64;
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -87,19 +90,35 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jp][r] = 0.f;
 
-  // BNF: per-channel constants in LDS ([7][64]: mean, rstd, coef0..2, sign scale / shift); a thread always handles the same 8-channel chunk
-  float* bnc = reinterpret_cast<float*>(dYs + TH * TW * PDY);
-  const bool sign = BNF && p.sg_scale != nullptr;
+  // BNF: a thread always handles the same 8-channel chunk of a pixel (NTH is a multiple of the chunks per pixel), so its
+  // per-channel constants live in registers as pairs for the packed fp32 instructions: mean, rstd, coef0..2, sign scale / shift
+  // (from LDS they cost 56 dword reads per chunk, 1.5 us per tile of LDS bandwidth next to the fragment reads)
+  static_assert(NTH % (DYB / 16) == 0, "chunk index must not depend on k");
+  constexpr bool sign = BNF == 2;
+  f32x2 k_mean[4], k_rstd[4], k_c0[4], k_c1[4], k_c2[4], k_ss[sign ? 4 : 1], k_sh[sign ? 4 : 1];
+  unsigned keep[4];  // packed-half mask of the channels below N
   if constexpr (BNF) {
-    for (int i = tid; i < 7 * 64; i += NTH) {
-      const int c = min(i & 63, p.N - 1), f = i >> 6;
-      bnc[i] = f == 0 ? p.mean[c] : f == 1 ? p.rstd[c] : f < 5 ? p.coef[(f - 2) * p.N + c] : !sign ? 0.f : f == 5 ? p.sg_scale[c] : p.sg_shift[c];
+    const int cbase = (tid % (DYB / 16)) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(cbase + e, p.N - 1);
+      k_mean[e >> 1][e & 1] = p.mean[c];
+      k_rstd[e >> 1][e & 1] = p.rstd[c];
+      k_c0[e >> 1][e & 1] = p.coef[c];
+      k_c1[e >> 1][e & 1] = p.coef[p.N + c];
+      k_c2[e >> 1][e & 1] = p.coef[2 * p.N + c];
+      if constexpr (sign) {
+        k_ss[e >> 1][e & 1] = p.sg_scale[c];
+        k_sh[e >> 1][e & 1] = p.sg_shift[c];
+      }
     }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) keep[h] = (cbase + 2 * h < p.N ? 0xffffu : 0u) | (cbase + 2 * h + 1 < p.N ? 0xffff0000u : 0u);
   }
   const half_t* __restrict__ raw = static_cast<const half_t*>(p.raw);
   const half_t* __restrict__ yout = static_cast<const half_t*>(p.yout);
 
-  uint4 rp[PCH], rd[DCH], rx[BNF ? DCH : 1], ry[BNF ? DCH : 1];
+  uint4 rp[PCH], rd[DCH], rx[BNF ? DCH : 1], ry[BNF == 1 ? DCH : 1];
   unsigned inside = 0;  // bit k: chunk k of the loaded tile lies inside the output image (outside: dY stays zero, no transform)
   auto load_tile = [&](int tile) {
     inside = 0;
@@ -130,27 +149,37 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
         v = *reinterpret_cast<const uint4*>(dy + off);
         if constexpr (BNF) {
           xr = *reinterpret_cast<const uint4*>(raw + off);
-          if (p.relu && !sign) yr = *reinterpret_cast<const uint4*>(yout + off);
+          if constexpr (BNF == 1) { if (p.relu) yr = *reinterpret_cast<const uint4*>(yout + off); }
         }
       }
       rd[k] = v;
-      if constexpr (BNF) { rx[k] = xr; ry[k] = yr; }
+      if constexpr (BNF) rx[k] = xr;
+      if constexpr (BNF == 1) ry[k] = yr;
     }
   };
   // the gradient w.r.t. the conv output from (dY, conv output, ReLU mask): bn.hip bn_bwd_apply_k's arithmetic
-  auto bn_transform = [&](uint4 v, uint4 xr, uint4 yr, int cc) -> uint4 {
-    const half8_t gv = __builtin_bit_cast(half8_t, v), xv = __builtin_bit_cast(half8_t, xr), yv = __builtin_bit_cast(half8_t, yr);
-    half8_t o;
+  auto bn_transform = [&](uint4 v, uint4 xr, uint4 yr) -> uint4 {
+    const unsigned gw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xr.x, xr.y, xr.z, xr.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
+    unsigned ow[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = cc * 8 + e;
-      float dz = (float)gv[e];
-      if (p.relu && !sign && !((float)yv[e] > 0.f)) dz = 0.f;
-      if (sign && !((float)xv[e] * bnc[320 + c] + bnc[384 + c] > 0.f)) dz = 0.f;
-      const float xhat = ((float)xv[e] - bnc[c]) * bnc[64 + c];
-      o[e] = c < p.N ? (half_t)(bnc[128 + c] * (dz - bnc[192 + c] - xhat * bnc[256 + c])) : (half_t)0.f;
+    for (int h = 0; h < 4; ++h) {
+      const half2_t g2 = __builtin_bit_cast(half2_t, gw[h]), x2 = __builtin_bit_cast(half2_t, xw[h]), y2 = __builtin_bit_cast(half2_t, yw[h]);
+      f32x2 dz = {(float)g2[0], (float)g2[1]};
+      const f32x2 xf = {(float)x2[0], (float)x2[1]};
+      if constexpr (sign) {
+        const f32x2 z = xf * k_ss[h] + k_sh[h];  // (the build has -ffp-contract=off: mul, add as in bn_bwd_apply_k)
+        dz[0] = z[0] > 0.f ? dz[0] : 0.f;
+        dz[1] = z[1] > 0.f ? dz[1] : 0.f;
+      } else if (p.relu) {
+        dz[0] = (float)y2[0] > 0.f ? dz[0] : 0.f;
+        dz[1] = (float)y2[1] > 0.f ? dz[1] : 0.f;
+      }
+      const f32x2 xhat = (xf - k_mean[h]) * k_rstd[h];
+      const f32x2 o = k_c0[h] * (dz - k_c1[h] - xhat * k_c2[h]);
+      const half2_t oh = {(half_t)o[0], (half_t)o[1]};
+      ow[h] = __builtin_bit_cast(unsigned, oh) & keep[h];
     }
-    return __builtin_bit_cast(uint4, o);
+    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
       const int pix = c / (DYB / 16), cc = c - pix * (DYB / 16);
       uint4 v = rd[k];
       if constexpr (BNF) {
-        if (inside & (1u << k)) v = bn_transform(v, rx[k], ry[k], cc);  // (a pixel outside the image has no gradient: the affine part of the
+        if (inside & (1u << k)) v = bn_transform(v, rx[k], ry[BNF == 1 ? k : 0]);  // (a pixel outside the image has no gradient: the affine part of the
       }                                                                 // BatchNorm backward would otherwise leave -c0 * (c1 + xhat * c2) there)
       *reinterpret_cast<uint4*>(dYs + pix * PDY + cc * 16) = v;
     }
@@ -225,13 +254,13 @@ __global__ __launch_bounds__(512) void conv_s2d_wgrad_k(const S2dWgradParams p) 
   }
 }
 
-template <int TAPS, int NT, bool BNF>
+template <int TAPS, int NT, int BNF>
 int launch(const S2dWgradParams& p, hipStream_t s) {
   constexpr int PH = TH + TAPS - 1;
   constexpr int PATCH = ((PH * PW * PPITCH + 1023) / 1024) * 1024;
   constexpr int DYS = TH * TW * (NT == 1 ? 64 : 192);
   constexpr int RED = NT * 32 * TAPS * 64 * 4;
-  constexpr int LDS = (PATCH + DYS + 7 * 64 * 4) > RED ? (PATCH + DYS + 7 * 64 * 4) : RED;
+  constexpr int LDS = (PATCH + DYS) > RED ? (PATCH + DYS) : RED;
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (LDS > 64 * 1024 && !attr_done) {
@@ -273,9 +302,13 @@ int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, 
   p.sg_scale = sg_scale; p.sg_shift = sg_shift;
   if (raw != nullptr) {
     if (!mean || !rstd || !coef || (relu && !yout && !sg_scale) || (sg_scale && !sg_shift)) return AM_ERR_ARG;
-    if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, true>(p, s) : launch<4, 1, true>(p, s);
-    return g->ntaps == 3 ? launch<3, 2, true>(p, s) : launch<4, 2, true>(p, s);
+    if (sg_scale != nullptr) {
+      if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, 2>(p, s) : launch<4, 1, 2>(p, s);
+      return g->ntaps == 3 ? launch<3, 2, 2>(p, s) : launch<4, 2, 2>(p, s);
+    }
+    if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, 1>(p, s) : launch<4, 1, 1>(p, s);
+    return g->ntaps == 3 ? launch<3, 2, 1>(p, s) : launch<4, 2, 1>(p, s);
   }
-  if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, false>(p, s) : launch<4, 1, false>(p, s);
-  return g->ntaps == 3 ? launch<3, 2, false>(p, s) : launch<4, 2, false>(p, s);
+  if (g->N <= 32) return g->ntaps == 3 ? launch<3, 1, 0>(p, s) : launch<4, 1, 0>(p, s);
+  return g->ntaps == 3 ? launch<3, 2, 0>(p, s) : launch<4, 2, 0>(p, s);
 }
