@@ -122,7 +122,7 @@ int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x, const void
  * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 (retired), 5 (retired),
  * 6 conv_gemm2_k, 7 (retired), 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
  * 11 conv_ring16_k<256,256>, 12 conv_ring16_k<256,128>, 13 wgrad_ring_k, 14 conv_wgrad_k (register-staged), 15 conv_s2d_wgrad_k,
- * 16 conv_halo_k. */
+ * 16 conv_halo_k, 17 conv_patch_wgrad_k. */
 int am_conv_last_variant(void);
 
 /* Process-wide A/B switches between kernels that compute the same result (diagnostic / tuning use: tests pin a kernel, bench
@@ -136,14 +136,17 @@ int am_conv_last_variant(void);
  *                  atomically into ONE zero-filled slab (0: always; a huge value: never).
  *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256;
  *   AM_TUNE_HALO_MIN_TILES 3x3 / stride-1 layers with 64 < N <= 128 take the halo-staged kernel (conv_halo_k) from this many 8x32-pixel
- *                          tiles on (default 256; a huge value sends them to the ring kernel). */
+ *                          tiles on (default 256; a huge value sends them to the ring kernel).
+ *   AM_TUNE_PATCH_WGRAD_MIN_TILES the weight gradient of 64 -> 64 channel 3x3 / stride-1 layers takes the patch-staged kernel
+ *                          (conv_patch_wgrad_k) from this many 8x32-pixel tiles on (default 512; a huge value: never). */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
 #define AM_TUNE_WGRAD_MAX_SLABS 3
 #define AM_TUNE_RING_SHORT_K 4
 #define AM_TUNE_HALO_MIN_TILES 5
-#define AM_TUNE_COUNT 6
+#define AM_TUNE_PATCH_WGRAD_MIN_TILES 6
+#define AM_TUNE_COUNT 7
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 

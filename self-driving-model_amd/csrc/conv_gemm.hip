@@ -538,13 +538,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 // nn.Conv2d weight layout out[n][c][t] (OIHW: t = kh * KW + kw) from the packed k = t * krun + c.  The re-layout is a permutation
 // INSIDE an output-channel row, so a workgroup owns (a part of) one row: slab reads coalesced along k, the permutation through
 // LDS, the read-modify-write of `out` coalesced again.  grid = (parts, N); a part covers whole taps' worth of channels.
-constexpr int WR_CH = 32;  // channels per part: a part handles channels [c0, c0 + WR_CH) of every tap -> 4 * WR_CH * ntaps floats of LDS
+// wr_ch = channels per part: a part handles channels [c0, c0 + wr_ch) of every tap -> 4 * wr_ch * ntaps floats of LDS.  32 by default;
+// 16 when the slabs are many and the rows few (conv_patch_wgrad_k: 256 slabs x 64 rows -- twice the workgroups to hide the latency
+// of 64 dependent slab reads per wave; a part's reads are then 64-byte pieces)
 
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int Ktot, int krun,
-                                                      int cin, int ntaps, float scale, float* __restrict__ out, int accumulate) {
+                                                      int cin, int ntaps, float scale, float* __restrict__ out, int accumulate, int wr_ch) {
   extern __shared__ float row[];  // [4 chunk groups][cpart * ntaps] in output order
-  const int n = blockIdx.y, c0 = blockIdx.x * WR_CH;
-  const int cpart = min(WR_CH, cin - c0);
+  const int n = blockIdx.y, c0 = blockIdx.x * wr_ch;
+  const int cpart = min(wr_ch, cin - c0);
   const int nel = cpart * ntaps;
   const float* src = ws + (size_t)n * Ktot;
   // wave w sums the chunks s = w, w + 4, ...: a wave-instruction reads 64 consecutive packed k of one slab (256 B), eight of
@@ -603,6 +605,8 @@ int launch_wgrad(const WgradParams& p0, hipStream_t s, bool plan_only = false) {
 
 int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
                            bool plan_only, hipStream_t s);  // conv_wgrad_ring.hip
+int am_conv_patch_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
+                            bool plan_only, hipStream_t s);  // conv_patch_wgrad.hip
 int am_conv_s2d_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, const void* yout, const void* raw, const float* mean,
                           const float* rstd, const float* coef, int relu, const float* sg_scale, const float* sg_shift, float scale, float* dw,
                           hipStream_t s);  // conv_s2d_wgrad.hip
@@ -624,6 +628,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,
     /* AM_TUNE_RING_SHORT_K */ 8,
     /* AM_TUNE_HALO_MIN_TILES */ 256,
+    /* AM_TUNE_PATCH_WGRAD_MIN_TILES */ 512,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }
@@ -694,8 +699,9 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
 
 // Shared dispatcher of am_conv_wgrad (atomic form: ws == nullptr) and am_conv_wgrad_ws (slab form).  plan_only: launches nothing,
 // returns the number of pixel chunks (= slabs) of the kernel that would run, 0 when that kernel has no slab form.
+// *own_slabs (plan_only): the kernel wants one slab per workgroup whatever their number (it has no pixel chunks to merge).
 static int wgrad_dispatch(const am_conv_geom* g, int dtype, const void* x, const void* dy, float scale, float* dw, float* ws,
-                          long long ws_stride, bool plan_only, hipStream_t s) {
+                          long long ws_stride, bool plan_only, hipStream_t s, bool* own_slabs = nullptr) {
   const int es = dtype == AM_F16 ? 2 : 4;
   WgradParams p;
   p.g = *g;
@@ -711,7 +717,12 @@ static int wgrad_dispatch(const am_conv_geom* g, int dtype, const void* x, const
       const int rc = am_conv_s2d_wgrad_f16(g, x, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, scale, dw, s);
       if (rc != AM_ERR_UNSUPPORTED) return rc;
     }
-    const int rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, ws, ws_stride, plan_only, s);  // LDS-DMA ring kernel: N % 128 == 0, long contractions
+    int rc = am_conv_patch_wgrad_f16(g, x, dy, scale, dw, ws, ws_stride, plan_only, s);  // 64 -> 64 channels 3x3 / s1: operands read once
+    if (rc != AM_ERR_UNSUPPORTED) {
+      if (own_slabs) *own_slabs = true;
+      return rc;
+    }
+    rc = am_conv_wgrad_ring_f16(g, x, dy, scale, dw, ws, ws_stride, plan_only, s);  // LDS-DMA ring kernel: N % 128 == 0, long contractions
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     if (g->N > 64) return launch_wgrad<half_t, 128, 4>(p, s, plan_only);
     return launch_wgrad<half_t, 64, 4>(p, s, plan_only);
@@ -742,9 +753,10 @@ extern "C" int am_conv_wgrad_workspace_bytes(const am_conv_geom* g, int dtype, l
   if (!bytes || g->ntaps <= 0) return AM_ERR_ARG;
   *bytes = 0;
   if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
-  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
+  bool own = false;
+  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr, &own);
   if (chunks < 0) return chunks;
-  *bytes = (long long)ws_slabs(chunks) * g->N * g->ntaps * g->krun * 4;
+  *bytes = (long long)(own ? chunks : ws_slabs(chunks)) * g->N * g->ntaps * g->krun * 4;
   return AM_OK;
 }
 
@@ -757,10 +769,11 @@ extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x,
   if ((g->ldo * es) % 16 != 0 || (g->y_coff * es) % 16 != 0) return AM_ERR_ARG;
   if ((long long)g->B * g->MH * g->MW == 0) return AM_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr);
+  bool own = false;
+  const int chunks = wgrad_dispatch(g, dtype, nullptr, nullptr, 1.f, nullptr, nullptr, 0, true, nullptr, &own);
   if (chunks < 0) return chunks;
   if (chunks == 0) return AM_ERR_UNSUPPORTED;  // first-layer kernel: atomic form only (caller: am_conv_wgrad + its own unpack)
-  const int slabs = ws_slabs(chunks);
+  const int slabs = own ? chunks : ws_slabs(chunks);
   const long long Ktot = (long long)g->ntaps * g->krun, stride = (long long)g->N * Ktot;
   if (!workspace || workspace_bytes < slabs * stride * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return AM_ERR_ARG;
   float* ws = static_cast<float*>(workspace);
@@ -771,10 +784,11 @@ extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x,
     rc = wgrad_dispatch(g, dtype, x, dy, 1.f, ws, nullptr, 0, false, s);
   }
   if (rc != AM_OK) return rc;
-  const int parts = am_cdiv(cin, WR_CH);
-  const size_t lds = 4 * (size_t)(cin < WR_CH ? cin : WR_CH) * g->ntaps * sizeof(float);
+  const int wr_ch = own ? 16 : 32;
+  const int parts = am_cdiv(cin, wr_ch);
+  const size_t lds = 4 * (size_t)(cin < wr_ch ? cin : wr_ch) * g->ntaps * sizeof(float);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(parts, g->N), dim3(256), lds, s, ws, slabs, stride, (int)Ktot, g->krun, cin, g->ntaps, scale,
-                     dw_oihw, accumulate);
+                     dw_oihw, accumulate, wr_ch);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }

@@ -1,0 +1,220 @@
+// Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (ResNet layer1) on gfx950, f16.
+//
+// dW[n][t*64 + c] = sum over output pixels of dY[pixel][n] * X[pixel + tap t][c]: a [64] x [576] result contracted over
+// B*H*W pixels (920 k at B = 16, 720p), i.e. tiny output and a very long reduction.  The generic conv_wgrad_k gathers X once
+// per tap (nine reads of the activation through the load path) and splits the pixels over ~1000 workgroups that meet in
+// fp32 atomics: 122 us at B = 16 (555 TFLOP/s) for 236 MB of operands.  Here, as in conv_s2d_wgrad.hip, a persistent
+// workgroup walks 8x32-pixel output tiles, stages each tile's dY block and its 10x34 input patch ONCE in LDS (pixel-major,
+// pitch 192 B = 64 mod 128: both MFMA operands come out of the ds_read_b64_tr_b16 transposing read) and keeps the whole
+// gradient in registers: twelve waves = 2 output-channel blocks x 3 horizontal taps x 2 input-channel blocks, each with the
+// three vertical taps of its column (3 accumulators of 32x32).  A wave walks the patch rows once: the row's fragment feeds
+// the three taps (output rows r, r-1, r-2), so an MFMA costs 0.75 KB of LDS reads.  The next tile's global loads are issued
+// before the MFMA phase and land under it.  One flush per workgroup: plain stores into its slab of the caller's workspace
+// (am_conv_wgrad_ws; wgrad_reduce_k sums the slabs) or, without a workspace, fp32 atomics.
+#include "am_common.h"
+
+namespace apw {
+
+constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
+constexpr int PITCH = 192;                 // LDS bytes per pixel (128 B of channels + 64 B pad)
+constexpr int NW = 12, NTH = NW * 64;
+constexpr int PATCH_BYTES = PH * PW * PITCH;  // 65,280
+constexpr int DY_BYTES = TH * TW * PITCH;     // 49,152
+constexpr int LDS_BYTES = PATCH_BYTES + DY_BYTES;
+constexpr int PCHUNKS = PH * PW * 8, DCHUNKS = TH * TW * 8;  // 16-byte chunks per tile
+constexpr int PCH = (PCHUNKS + NTH - 1) / NTH, DCH = (DCHUNKS + NTH - 1) / NTH;
+constexpr int KTOT = 9 * 64;
+
+struct Params {
+  const void* x;    // [B, H, W, ldi] halves (+ x_coff)
+  const void* dy;   // [B, H, W, ldo] halves (+ y_coff)
+  float* dw;        // atomic form: packed [64][576] fp32, accumulated (scaled)
+  float* ws;        // slab form: workgroup b stores its unscaled partial at ws + b * ws_stride
+  long long ws_stride;
+  float scale;
+  int B, H, W, ldi, x_coff, ldo, y_coff;
+  int tiles_y, tiles_x, ntiles;
+};
+
+typedef __attribute__((address_space(3))) s4v* lds_s4v;
+
+// 32 channels x 8 pixels of a pixel-major LDS tile as an MFMA operand (lane: channel lane % 32, pixels 8 * (lane / 32) ..+7)
+__device__ __forceinline__ half8_t tr_frag(const char* lo_addr) {
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr + 4 * PITCH));
+  const half4_t l4 = __builtin_bit_cast(half4_t, lo), h4 = __builtin_bit_cast(half4_t, hi);
+  return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+__global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* patch = smem;
+  char* dYs = smem + PATCH_BYTES;
+
+  const half_t* __restrict__ x = static_cast<const half_t*>(p.x) + p.x_coff;
+  const half_t* __restrict__ dy = static_cast<const half_t*>(p.dy) + p.y_coff;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int nblk = wid & 1, cblk = (wid >> 1) & 1, kx = wid >> 2;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // which patch pixel / dY pixel and 16-byte piece a thread fetches never changes: (row << 8 | column) per chunk
+  int ppos[PCH];
+#pragma unroll
+  for (int k = 0; k < PCH; ++k) {
+    const int pix = (tid + k * NTH) >> 3;
+    const int prow = pix / PW;
+    ppos[k] = (prow << 8) | (pix - prow * PW);
+  }
+  const int sub = (tid & 7) * 8;  // NTH is a multiple of 8: the channel piece does not depend on k
+
+  // (a second register set, so that a tile's loads have two tile periods to land instead of one MFMA phase, does not fit: 168
+  // registers at three waves per SIMD, 114 spilled)
+  uint4 rpA[PCH], rdA[DCH];
+  auto load_tile = [&](int tile, uint4 (&rp)[PCH], uint4 (&rd)[DCH]) {
+    const int img = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - img * (p.tiles_y * p.tiles_x);
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const long long ibase = (long long)img * p.H * p.W;
+    // every load is issued unconditionally from a clamped address and zeroed afterwards: a branch around a load would
+    // serialise the memory round trips
+#pragma unroll
+    for (int k = 0; k < PCH; ++k) {
+      const int iy = ty * TH + (ppos[k] >> 8) - 1, ix = tx * TW + (ppos[k] & 255) - 1;
+      const bool ok = (tid + k * NTH) < PCHUNKS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long off = ok ? (ibase + (long long)iy * p.W + ix) * p.ldi + sub : 0;
+      const uint4 v = *reinterpret_cast<const uint4*>(x + off);
+      rp[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int pix = (tid + k * NTH) >> 3;
+      const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
+      const bool ok = (tid + k * NTH) < DCHUNKS && oy < p.H && ox < p.W;
+      const long long off = ok ? (ibase + (long long)oy * p.W + ox) * p.ldo + sub : 0;
+      const uint4 v = *reinterpret_cast<const uint4*>(dy + off);
+      rd[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&](const uint4 (&rp)[PCH], const uint4 (&rd)[DCH]) {
+#pragma unroll
+    for (int k = 0; k < PCH; ++k) {
+      const int c = tid + k * NTH;
+      if (c < PCHUNKS) *reinterpret_cast<uint4*>(patch + (c >> 3) * PITCH + (c & 7) * 16) = rp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int c = tid + k * NTH;
+      if (c < DCHUNKS) *reinterpret_cast<uint4*>(dYs + (c >> 3) * PITCH + (c & 7) * 16) = rd[k];
+    }
+  };
+
+  // tiles of one XCD (workgroup b runs on XCD b % 8) are consecutive, so the halos its tiles share are hits in that XCD's L2
+  int tile, tend, tstep;
+  if ((gridDim.x & 7) == 0) {
+    const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+    tile = xcd * per + (blockIdx.x >> 3);
+    tend = min(p.ntiles, (xcd + 1) * per);
+    tstep = gridDim.x >> 3;
+  } else {
+    tile = blockIdx.x; tend = p.ntiles; tstep = gridDim.x;
+  }
+
+  // lane's byte offset inside a pixel-major tile: pixel 8 * (gq >> 1) + q, channels (gq & 1) * 16 + 4 * pp ..+3 of a 32-block
+  const int frag_off = (8 * (gq >> 1) + q) * PITCH + ((gq & 1) * 16 + 4 * pp) * 2;
+  const char* a_base = dYs + frag_off + nblk * 64;
+  const char* b_base = patch + frag_off + kx * PITCH + cblk * 64;
+
+  auto mfma_phase = [&]() {
+    // software pipeline over the 2 x 10 (pixel half, patch row) steps: the fragments of step s + 1 are requested before the
+    // MFMAs of step s are issued (left alone the compiler orders it read, wait for everything, multiply)
+    half8_t a[2][TH];
+    half8_t bn = tr_frag(b_base), an = tr_frag(a_base);
+#pragma unroll
+    for (int st = 0; st < 2 * PH; ++st) {
+      const int xh = st / PH, pr = st % PH;
+      const half8_t b = bn;
+      if (pr < TH) a[xh][pr] = an;
+      if (st + 1 < 2 * PH) {
+        const int xh1 = (st + 1) / PH, pr1 = (st + 1) % PH;
+        bn = tr_frag(b_base + (pr1 * PW + xh1 * 16) * PITCH);
+        if (pr1 < TH) an = tr_frag(a_base + (pr1 * TW + xh1 * 16) * PITCH);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests above the MFMAs: the wait before them then counts only the older reads
+      // patch row pr feeds output row pr - ky through vertical tap ky
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int r = pr - ky;
+        if (r >= 0 && r < TH) acc[ky] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[xh][r], b, acc[ky], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (tile < tend) load_tile(tile, rpA, rdA);
+  for (; tile < tend; tile += tstep) {
+    __syncthreads();  // previous tile's fragment reads are done
+    store_tile(rpA, rdA);
+    __syncthreads();
+    if (tile + tstep < tend) load_tile(tile + tstep, rpA, rdA);  // in flight during the MFMA phase
+    mfma_phase();
+  }
+
+  // ---- flush: a wave owns its (channel block, taps) outright -- no reduction across waves ----
+  float* slab = p.ws ? p.ws + (long long)blockIdx.x * p.ws_stride : nullptr;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int k = (ky * 3 + kx) * 64 + cblk * 32 + (lane & 31);
+      if (slab) slab[n * KTOT + k] = acc[ky][r];
+      else atomicAdd(p.dw + n * KTOT + k, acc[ky][r] * p.scale);
+    }
+}
+
+}  // namespace apw
+
+// Called by wgrad_dispatch (conv_gemm.hip).  plan_only: nothing is launched, the return value is the number of slabs (one per
+// workgroup) the slab form writes.  ws != NULL: slab form (unscaled partials at ws + b * ws_stride); else atomics into dw.
+// Returns AM_ERR_UNSUPPORTED unless the geometry is a dense 3x3 / stride 1 / pad 1 convolution with 64 input and output channels
+// (canonical tap order) large enough to fill the chip.
+int am_conv_patch_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
+                            bool plan_only, hipStream_t s) {
+  using namespace apw;
+  if (g->ntaps != 9 || g->pix_shift != 31 || g->N != 64 || g->krun != 64 || g->osplit > 0) return AM_ERR_UNSUPPORTED;
+  if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
+  if (g->MH != g->IH || g->MW != g->IW || g->OH != g->IH || g->OW != g->IW) return AM_ERR_UNSUPPORTED;
+  if (g->ldi % 8 != 0 || g->x_coff % 8 != 0 || g->ldo % 8 != 0 || g->y_coff % 8 != 0 || g->ldi - g->x_coff < 64 || g->ldo - g->y_coff < 64)
+    return AM_ERR_UNSUPPORTED;
+  for (int t = 0; t < 9; ++t)
+    if (g->dy[t] != t / 3 - 1 || g->dx[t] != t % 3 - 1) return AM_ERR_UNSUPPORTED;
+  Params p;
+  p.tiles_y = am_cdiv(g->IH, TH);
+  p.tiles_x = am_cdiv(g->IW, TW);
+  p.ntiles = g->B * p.tiles_y * p.tiles_x;
+  const int min_tiles = am_tuning(AM_TUNE_PATCH_WGRAD_MIN_TILES);
+  if (p.ntiles < min_tiles) return AM_ERR_UNSUPPORTED;  // below ~two tiles per CU the flush (one slab per workgroup) outweighs the single read
+  // tiles that overhang the image waste their MFMAs on it: at most 20 % unless the caller forces the kernel
+  if (min_tiles > 1 && (long long)g->IH * g->IW * 100 < (long long)p.tiles_y * TH * p.tiles_x * TW * 80) return AM_ERR_UNSUPPORTED;
+  const int grid = p.ntiles < 256 ? p.ntiles : 256;  // persistent: one 12-wave workgroup per CU
+  if (plan_only) return grid;
+  p.x = x; p.dy = dy; p.dw = dw; p.ws = ws; p.ws_stride = ws_stride; p.scale = scale;
+  p.B = g->B; p.H = g->IH; p.W = g->IW; p.ldi = g->ldi; p.x_coff = g->x_coff; p.ldo = g->ldo; p.y_coff = g->y_coff;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  g_am_conv_variant = AM_CV_WGRAD_PATCH_C64;
+  hipLaunchKernelGGL(conv_patch_wgrad_k, dim3(grid), dim3(NTH), LDS_BYTES, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}

@@ -398,7 +398,7 @@ def _timed(kind: str, flops: float, fn):
     e0.record()
     fn()
     e1.record()
-    TIMER.records.append((kind, flops, e0, e1, CONV_KERNEL_NAMES.get(_L().am_conv_last_variant(), "?") if kind != "conv_wgrad" else "weight gradients (wgrad_ring_k, conv_wgrad_k, conv_s2d_wgrad_k)"))
+    TIMER.records.append((kind, flops, e0, e1, CONV_KERNEL_NAMES.get(_L().am_conv_last_variant(), "?") if kind != "conv_wgrad" else "weight gradients (wgrad_ring_k, conv_wgrad_k, conv_s2d_wgrad_k, conv_patch_wgrad_k)"))
 
 
 def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None, k_real: Optional[int] = None, kind: str = "conv_gemm"):

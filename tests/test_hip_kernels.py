@@ -935,6 +935,54 @@ def test_ring_kernel_generations_agree(case):
     assert rel_err(res[1][0][:1].permute(0, 3, 1, 2), yr) < 2e-3
 
 
+@pytest.mark.parametrize("shape", [(3, 45, 70), (2, 64, 96), (1, 8, 32), (5, 19, 33)])
+def test_patch_staged_weight_gradient_c64_vs_torch_and_generic_kernel(shape):
+    """conv_patch_wgrad_k (64 -> 64 channels, 3x3 / stride 1: dY tile and input patch staged once per 8x32-pixel tile, the whole
+    gradient in registers, one slab per workgroup) against torch's conv2d weight gradient and against the generic kernel on the
+    same operands, in the workspace form and in the atomic form, on maps with ragged tiles in both directions (a pixel outside
+    the map contributes nothing; the patch border is the zero padding) and with padded channel strides."""
+    import ctypes
+    from self_driving_model_amd.hip import conv as hc
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 64, H, W, generator=g).half().float()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).requires_grad_()
+    dyr = (torch.randn(B, 64, H, W, generator=g) * 0.5).half().float()
+    (F.conv2d(x, w, None, stride=1, padding=1) * dyr).sum().backward()
+    spec = hc.ConvSpec(64, 64, 3, 1, 1)
+    xd, dyd = nhwc(x, torch.float16), nhwc(dyr, torch.float16, ld=64)
+    geom = hc.fwd_geom(spec, B, H, W, 64, 64, 2)
+    L = hc._L()
+    wparam = torch.nn.Parameter(torch.zeros(64, 64, 3, 3, device=_dev()))
+    res = {}
+    old = L.am_get_tuning(6)
+    try:
+        for name, min_tiles in (("conv_patch_wgrad_k", 1), ("conv_wgrad_k", 1 << 30)):
+            L.am_set_tuning(6, min_tiles)  # AM_TUNE_PATCH_WGRAD_MIN_TILES
+            nbytes = ctypes.c_longlong(0)
+            L.am_conv_wgrad_workspace_bytes(ctypes.byref(geom), hc.dt_code(torch.float16), ctypes.byref(nbytes))
+            if min_tiles == 1:  # one slab per workgroup = per tile up to 256
+                assert nbytes.value == min(256, B * ((H + 7) // 8) * ((W + 31) // 32)) * 64 * 576 * 4
+            a = hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec).clone()
+            launched_kernel(name, what=f"patch wgrad {shape}")
+            b = hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec).clone()
+            if min_tiles == 1:  # (the generic kernel's many pixel chunks meet in atomics: not reproducible bit for bit)
+                assert torch.equal(a, b), "the slab sum must be bitwise reproducible"
+            dwp = torch.zeros(64, 576, dtype=torch.float32, device=_dev())
+            hc.conv_wgrad(geom, xd, dyd, 0.5, dwp)  # atomic form, packed layout
+            launched_kernel(name, what=f"patch wgrad atomic {shape}")
+            res[name] = (a, hc.unpack_wgrad(dwp, spec, torch.float16))
+    finally:
+        L.am_set_tuning(6, old)
+    torch.cuda.synchronize()
+    ref = 0.5 * w.grad
+    for name, (ws_form, atomic_form) in res.items():
+        assert rel_err(ws_form, ref) < 2e-3, (name, rel_err(ws_form, ref))
+        assert rel_err(atomic_form, ws_form) < 1e-5, (name, rel_err(atomic_form, ws_form))
+    # same f16 products summed in fp32 in a different order
+    assert rel_err(res["conv_patch_wgrad_k"][0], res["conv_wgrad_k"][0]) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1, 4, 128, 160, torch.float16, "wgrad_ring_k"), (512, 512, 3, 1, 1, 6, 46, 80, torch.float16, "wgrad_ring_k"),
                                   (64, 64, 3, 1, 1, 2, 96, 128, torch.float16, "conv_wgrad_k"), (256, 14, 1, 1, 0, 3, 23, 40, torch.float16, "conv_wgrad_k"),
                                   (64, 128, 3, 2, 1, 2, 23, 40, torch.float32, "conv_wgrad_k")])
