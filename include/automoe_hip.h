@@ -435,7 +435,8 @@ int am_scale_inplace(float* x, long long n, float mul, const double* denom, am_s
 
 /* Packed conv operands from the fp32 master weight (hip/conv.py pack_fwd / pack_dgrad layouts; the reference keeps plain
  * OIHW nn.Conv2d weights, e.g. models/policy/trajectory_head.py:10-22): dst[i] = idx[i] < 0 ? 0 : (dtype)src[idx[i]].
- * One launch rebuilds every layout of a layer after an optimizer step. */
+ * One launch rebuilds every layout of a layer (or of a whole model) after an optimizer step.  idx and dst 16-byte aligned
+ * (AM_ERR_ARG otherwise): the kernel works in vectors of eight elements. */
 int am_gather_cast(int dtype, const float* src, const int* idx, void* dst, long long n, am_stream_t stream);
 
 #ifdef __cplusplus

@@ -481,14 +481,15 @@ __global__ __launch_bounds__(1024) void linear_group_bwd_input_k(const LinGroup 
   const int k = blockIdx.x * 64 + kx;
   const int m0 = blockIdx.y * MB;
   if (m0 >= M) return;
+  // both loads of an element unconditional (clamped row) and four elements per thread in flight: behind the row / mask branches
+  // each was a memory round trip of its own
+#pragma unroll 4
   for (int e = threadIdx.x; e < MB * N; e += 1024) {
     const int i = e / N, n = e - i * N;
-    float g = 0.f;
-    if (m0 + i < M) {
-      g = d.dy[(size_t)(m0 + i) * d.lddy + n] * d.gscale;
-      if (d.yact && !(d.yact[(size_t)(m0 + i) * d.ldya + n] > 0.f)) g = 0.f;
-    }
-    dz[e] = g;
+    const int m = min(m0 + i, M - 1);
+    const float gy = d.dy[(size_t)m * d.lddy + n];
+    const float ya = d.yact ? d.yact[(size_t)m * d.ldya + n] : 1.f;
+    dz[e] = (m0 + i < M && ya > 0.f) ? gy * d.gscale : 0.f;
   }
   __syncthreads();
   float acc[MB];
@@ -497,11 +498,18 @@ __global__ __launch_bounds__(1024) void linear_group_bwd_input_k(const LinGroup 
   const int nper = (N + BI_SLICES - 1) / BI_SLICES;
   const int nb = slice * nper, ne = min(N, nb + nper);
   if (k < K) {
-#pragma unroll 4
-    for (int n = nb; n < ne; ++n) {
-      const float wv = d.W[(size_t)n * K + k];
+    // eight weight loads in flight per batch (the four of `#pragma unroll 4` left the loop one memory round trip per 4 channels)
+    for (int n = nb; n < ne; n += 8) {
+      float wv[8];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) acc[i] += dz[i * N + n] * wv;
+      for (int j = 0; j < 8; ++j) wv[j] = d.W[(size_t)min(n + j, ne - 1) * K + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (n + j < ne) {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[i] += dz[i * N + n + j] * wv[j];
+        }
+      }
     }
   }
 #pragma unroll
@@ -521,35 +529,49 @@ __global__ __launch_bounds__(1024) void linear_group_bwd_input_k(const LinGroup 
 }
 
 // dW[n][k] += sum_m dz[m][n] x[m][k], dbias[n] += sum_m dz[m][n].  A thread owns one k-column and a block of GW_NB output
-// channels: its x column (up to GW_MR rows per pass) sits in registers and is reused for every channel of the block, dz values
-// are wave-uniform loads -- the thread-per-(n, k) form re-read x once per channel through a dependent M-loop (35 us per launch
-// on the policy heads).  grid (ceil(Kmax/256), ceil(Nmax/GW_NB), group).
+// channels: its x column (up to GW_MR rows per pass) sits in registers and is reused for every channel of the block.  The
+// [GW_MR][GW_NB] tile of dz (gscale and ReLU / dropout mask applied) is staged in LDS by one load per thread, all in flight at
+// once; read per element inside the channel / row loops (wave-uniform loads behind `break`s) every one of the 256 products waited
+// for its own memory round trip: 62 us per launch at M = 32 for 25 MFLOP.  Same products in the same order as before.
+// grid (ceil(Kmax/256), ceil(Nmax/GW_NB), group).
 constexpr int GW_NB = 8, GW_MR = 32;
+static_assert(GW_NB * GW_MR == 256, "one dz element per thread");
 __global__ __launch_bounds__(256) void linear_group_bwd_weight_k(const LinGroup grp, int M) {
   const am_tail_linear& d = grp.p[blockIdx.z];
   if (d.dW == nullptr) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int nb = blockIdx.y * GW_NB;
   if (nb >= d.N || (int)blockIdx.x * 256 >= d.K) return;
+  __shared__ __attribute__((aligned(16))) float dzs[GW_MR][GW_NB];
   const bool kok = k < d.K;
+  const int si = threadIdx.x >> 3, sj = threadIdx.x & 7;
   float acc[GW_NB], bacc[GW_NB];
 #pragma unroll
   for (int j = 0; j < GW_NB; ++j) { acc[j] = 0.f; bacc[j] = 0.f; }
   for (int m0 = 0; m0 < M; m0 += GW_MR) {
+    const bool sok = m0 + si < M && nb + sj < d.N;
+    const int sm = min(m0 + si, M - 1), sn = min(nb + sj, d.N - 1);
+    const float gy = d.dy[(size_t)sm * d.lddy + sn];
+    const float ya = d.yact ? d.yact[(size_t)sm * d.ldya + sn] : 1.f;
     float xv[GW_MR];
 #pragma unroll
     for (int i = 0; i < GW_MR; ++i) xv[i] = (kok && m0 + i < M) ? d.x[(size_t)(m0 + i) * d.ldx + k] : 0.f;
+    float g = gy * d.gscale;
+    if (!(ya > 0.f) || !sok) g = 0.f;
+    __syncthreads();  // the previous pass has read its tile
+    dzs[si][sj] = g;
+    __syncthreads();
+    const int rows = min(GW_MR, M - m0);
 #pragma unroll
-    for (int j = 0; j < GW_NB; ++j) {
-      const int n = nb + j;
-      if (n >= d.N) break;
+    for (int i = 0; i < GW_MR; ++i) {
+      if (i < rows) {  // (a row past M would add +0 products: skipped so that sums are those of the per-row loop)
+        const float4 g0 = *reinterpret_cast<const float4*>(&dzs[i][0]), g1 = *reinterpret_cast<const float4*>(&dzs[i][4]);
+        const float gv[GW_NB] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-      for (int i = 0; i < GW_MR; ++i) {
-        if (m0 + i >= M) break;
-        float g = d.dy[(size_t)(m0 + i) * d.lddy + n] * d.gscale;
-        if (d.yact && !(d.yact[(size_t)(m0 + i) * d.ldya + n] > 0.f)) g = 0.f;
-        acc[j] += g * xv[i];
-        bacc[j] += g;
+        for (int j = 0; j < GW_NB; ++j) {
+          acc[j] += gv[j] * xv[i];
+          bacc[j] += gv[j];
+        }
       }
     }
   }
