@@ -138,7 +138,10 @@ int am_conv_last_variant(void);
  *   AM_TUNE_HALO_MIN_TILES 3x3 / stride-1 layers with 64 < N <= 128 take the halo-staged kernel (conv_halo_k) from this many 8x32-pixel
  *                          tiles on (default 256; a huge value sends them to the ring kernel).
  *   AM_TUNE_PATCH_WGRAD_MIN_TILES the weight gradient of 64 -> 64 channel 3x3 / stride-1 layers takes the patch-staged kernel
- *                          (conv_patch_wgrad_k) from this many 8x32-pixel tiles on (default 512; a huge value: never). */
+ *                          (conv_patch_wgrad_k) from this many 8x32-pixel tiles on (default 512; a huge value: never); the same
+ *                          bound, in 8x16-pixel tiles, for the 128 -> 128 channel form.
+ *   AM_TUNE_PATCH_WGRAD_C128 1 (default): 128 -> 128 channel 3x3 / stride-1 layers take conv_patch_wgrad_k<128> (three workgroups
+ *                          per tile stream, one per horizontal tap), 0: wgrad_ring_k. */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
@@ -146,7 +149,8 @@ int am_conv_last_variant(void);
 #define AM_TUNE_RING_SHORT_K 4
 #define AM_TUNE_HALO_MIN_TILES 5
 #define AM_TUNE_PATCH_WGRAD_MIN_TILES 6
-#define AM_TUNE_COUNT 7
+#define AM_TUNE_PATCH_WGRAD_C128 7
+#define AM_TUNE_COUNT 8
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 

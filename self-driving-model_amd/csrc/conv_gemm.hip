@@ -629,6 +629,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_RING_SHORT_K */ 8,
     /* AM_TUNE_HALO_MIN_TILES */ 256,
     /* AM_TUNE_PATCH_WGRAD_MIN_TILES */ 512,
+    /* AM_TUNE_PATCH_WGRAD_C128 */ 1,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }

@@ -1,4 +1,5 @@
-// Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (ResNet layer1) on gfx950, f16.
+// Weight gradient of the C -> C channel 3x3 / stride 1 / pad 1 convolutions with C = 64 (ResNet layer1) and C = 128 (layer2) on
+// gfx950, f16.  The text below describes the C = 64 form; the C = 128 form follows it.
 //
 // dW[n][t*64 + c] = sum over output pixels of dY[pixel][n] * X[pixel + tap t][c]: a [64] x [576] result contracted over
 // B*H*W pixels (920 k at B = 16, 720p), i.e. tiny output and a very long reduction.  The generic conv_wgrad_k gathers X once
@@ -15,34 +16,35 @@
 // holds under MFMA load: 2.3 us), tile store + two barriers 0.6 us, 1.0 us waiting for the next tile's loads (all CUs request
 // their 76 KB in the same burst after the barrier: ~4 us to drain at HBM rate, the MFMA phase covers 3); per launch another
 // ~33 us of flush + reduce pass.
+//
+// C = 128 (layer2: [128] x [1152], 230 k pixels at B = 16): the gradient (590 KB of fp32) does not fit one CU's registers, so the
+// three horizontal taps go to three workgroups (blockIdx / G; the three of a tile stream share an XCD, i.e. an L2, because G is a
+// multiple of 8) that write disjoint column ranges of the same slab.  16 waves = 4 output-channel blocks x 4 input-channel blocks
+// with the three vertical taps as accumulators, 8x16-pixel tiles, a 10x16 patch window shifted by the tap (pitch 320 B = 64 mod
+// 128), 92 KB of LDS.  Replaces wgrad_ring_k on these layers (its 128x256 tiles over ~100 pixel chunks: 124 us + 32 us of reduce
+// pass at B = 16, 548 TFLOP/s).
 #include "am_common.h"
 
 namespace apw {
 
-constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
-constexpr int PITCH = 192;                 // LDS bytes per pixel (128 B of channels + 64 B pad)
-constexpr int NW = 12, NTH = NW * 64;
-constexpr int PATCH_BYTES = PH * PW * PITCH;  // 65,280
-constexpr int DY_BYTES = TH * TW * PITCH;     // 49,152
-constexpr int LDS_BYTES = PATCH_BYTES + DY_BYTES;
-constexpr int PCHUNKS = PH * PW * 8, DCHUNKS = TH * TW * 8;  // 16-byte chunks per tile
-constexpr int PCH = (PCHUNKS + NTH - 1) / NTH, DCH = (DCHUNKS + NTH - 1) / NTH;
-constexpr int KTOT = 9 * 64;
+constexpr int TH = 8, PH = TH + 2;
 
 struct Params {
   const void* x;    // [B, H, W, ldi] halves (+ x_coff)
   const void* dy;   // [B, H, W, ldo] halves (+ y_coff)
-  float* dw;        // atomic form: packed [64][576] fp32, accumulated (scaled)
-  float* ws;        // slab form: workgroup b stores its unscaled partial at ws + b * ws_stride
+  float* dw;        // atomic form: packed [C][9 * C] fp32, accumulated (scaled)
+  float* ws;        // slab form: tile stream j stores its unscaled partial at ws + j * ws_stride
   long long ws_stride;
   float scale;
   int B, H, W, ldi, x_coff, ldo, y_coff;
   int tiles_y, tiles_x, ntiles;
+  int streams;      // tile streams (= slabs); grid = streams * (KXB ? 3 : 1)
 };
 
 typedef __attribute__((address_space(3))) s4v* lds_s4v;
 
 // 32 channels x 8 pixels of a pixel-major LDS tile as an MFMA operand (lane: channel lane % 32, pixels 8 * (lane / 32) ..+7)
+template <int PITCH>
 __device__ __forceinline__ half8_t tr_frag(const char* lo_addr) {
   const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr));
   const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v)(lo_addr + 4 * PITCH));
@@ -50,16 +52,38 @@ __device__ __forceinline__ half8_t tr_frag(const char* lo_addr) {
   return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
 }
 
-__global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
+// C: channels (in = out).  TW: tile width.  KXB: the horizontal tap comes from the block index (three workgroups per tile stream,
+// patch = the TW columns of that tap) instead of the wave index (patch = TW + 2 columns).
+template <int C, int TW, bool KXB>
+struct Cfg {
+  static constexpr int CB = C / 32;                       // 32-channel blocks
+  static constexpr int NW = CB * CB * (KXB ? 1 : 3), NTH = NW * 64;
+  static constexpr int PW = KXB ? TW : TW + 2;
+  static constexpr int PITCH = C * 2 + 64;                // LDS bytes per pixel: = 64 (mod 128)
+  static constexpr int CPP = C / 8;                       // 16-byte chunks per pixel
+  static constexpr int PATCH_BYTES = PH * PW * PITCH, DY_BYTES = TH * TW * PITCH, LDS_BYTES = PATCH_BYTES + DY_BYTES;
+  static constexpr int PCHUNKS = PH * PW * CPP, DCHUNKS = TH * TW * CPP;
+  static constexpr int PCH = (PCHUNKS + NTH - 1) / NTH, DCH = (DCHUNKS + NTH - 1) / NTH;
+  static constexpr int KTOT = 9 * C;
+  static constexpr int XH = TW / 16;
+  static_assert(NTH % CPP == 0 && PITCH % 128 == 64 && TW % 16 == 0 && NTH <= 1024, "");
+};
+
+template <int C, int TW, bool KXB>
+__global__ __launch_bounds__((Cfg<C, TW, KXB>::NTH)) void conv_patch_wgrad_k(const Params p) {
+  using K = Cfg<C, TW, KXB>;
+  constexpr int NTH = K::NTH, PW = K::PW, PITCH = K::PITCH, CPP = K::CPP, PCH = K::PCH, DCH = K::DCH, CB = K::CB;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* patch = smem;
-  char* dYs = smem + PATCH_BYTES;
+  char* dYs = smem + K::PATCH_BYTES;
 
   const half_t* __restrict__ x = static_cast<const half_t*>(p.x) + p.x_coff;
   const half_t* __restrict__ dy = static_cast<const half_t*>(p.dy) + p.y_coff;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-  const int nblk = wid & 1, cblk = (wid >> 1) & 1, kx = wid >> 2;
+  const int nblk = wid % CB, cblk = (wid / CB) % CB;
+  const int kx = KXB ? (int)blockIdx.x / p.streams : wid / (CB * CB);
+  const int stream = KXB ? (int)blockIdx.x % p.streams : (int)blockIdx.x;
 
   f32x16 acc[3];
 #pragma unroll
@@ -71,11 +95,12 @@ __global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
   int ppos[PCH];
 #pragma unroll
   for (int k = 0; k < PCH; ++k) {
-    const int pix = (tid + k * NTH) >> 3;
+    const int pix = (tid + k * NTH) / CPP;
     const int prow = pix / PW;
     ppos[k] = (prow << 8) | (pix - prow * PW);
   }
-  const int sub = (tid & 7) * 8;  // NTH is a multiple of 8: the channel piece does not depend on k
+  const int sub = (tid % CPP) * 8;  // NTH is a multiple of CPP: the channel piece does not depend on k
+  const int xoff = KXB ? kx - 1 : -1;  // image column of patch column 0, relative to the tile
 
   // (a second register set, so that a tile's loads have two tile periods to land instead of one MFMA phase, does not fit: 168
   // registers at three waves per SIMD, 114 spilled)
@@ -89,17 +114,17 @@ __global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
     // serialise the memory round trips
 #pragma unroll
     for (int k = 0; k < PCH; ++k) {
-      const int iy = ty * TH + (ppos[k] >> 8) - 1, ix = tx * TW + (ppos[k] & 255) - 1;
-      const bool ok = (tid + k * NTH) < PCHUNKS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int iy = ty * TH + (ppos[k] >> 8) - 1, ix = tx * TW + (ppos[k] & 255) + xoff;
+      const bool ok = (tid + k * NTH) < K::PCHUNKS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const long long off = ok ? (ibase + (long long)iy * p.W + ix) * p.ldi + sub : 0;
       const uint4 v = *reinterpret_cast<const uint4*>(x + off);
       rp[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int k = 0; k < DCH; ++k) {
-      const int pix = (tid + k * NTH) >> 3;
-      const int oy = ty * TH + (pix >> 5), ox = tx * TW + (pix & 31);
-      const bool ok = (tid + k * NTH) < DCHUNKS && oy < p.H && ox < p.W;
+      const int pix = (tid + k * NTH) / CPP;
+      const int oy = ty * TH + pix / TW, ox = tx * TW + pix % TW;
+      const bool ok = (tid + k * NTH) < K::DCHUNKS && oy < p.H && ox < p.W;
       const long long off = ok ? (ibase + (long long)oy * p.W + ox) * p.ldo + sub : 0;
       const uint4 v = *reinterpret_cast<const uint4*>(dy + off);
       rd[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
@@ -109,45 +134,47 @@ __global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
 #pragma unroll
     for (int k = 0; k < PCH; ++k) {
       const int c = tid + k * NTH;
-      if (c < PCHUNKS) *reinterpret_cast<uint4*>(patch + (c >> 3) * PITCH + (c & 7) * 16) = rp[k];
+      if (c < K::PCHUNKS) *reinterpret_cast<uint4*>(patch + (c / CPP) * PITCH + (c % CPP) * 16) = rp[k];
     }
 #pragma unroll
     for (int k = 0; k < DCH; ++k) {
       const int c = tid + k * NTH;
-      if (c < DCHUNKS) *reinterpret_cast<uint4*>(dYs + (c >> 3) * PITCH + (c & 7) * 16) = rd[k];
+      if (c < K::DCHUNKS) *reinterpret_cast<uint4*>(dYs + (c / CPP) * PITCH + (c % CPP) * 16) = rd[k];
     }
   };
 
-  // tiles of one XCD (workgroup b runs on XCD b % 8) are consecutive, so the halos its tiles share are hits in that XCD's L2
+  // tiles of one XCD (workgroup b runs on XCD b % 8; the stream count is a multiple of 8 whenever this branch is taken, so all
+  // workgroups of a stream share it) are consecutive: the halos its tiles share are hits in that XCD's L2
   int tile, tend, tstep;
-  if ((gridDim.x & 7) == 0) {
-    const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
-    tile = xcd * per + (blockIdx.x >> 3);
+  if ((p.streams & 7) == 0) {
+    const int per = (p.ntiles + 7) >> 3, xcd = stream & 7;
+    tile = xcd * per + (stream >> 3);
     tend = min(p.ntiles, (xcd + 1) * per);
-    tstep = gridDim.x >> 3;
+    tstep = p.streams >> 3;
   } else {
-    tile = blockIdx.x; tend = p.ntiles; tstep = gridDim.x;
+    tile = stream; tend = p.ntiles; tstep = p.streams;
   }
 
   // lane's byte offset inside a pixel-major tile: pixel 8 * (gq >> 1) + q, channels (gq & 1) * 16 + 4 * pp ..+3 of a 32-block
   const int frag_off = (8 * (gq >> 1) + q) * PITCH + ((gq & 1) * 16 + 4 * pp) * 2;
   const char* a_base = dYs + frag_off + nblk * 64;
-  const char* b_base = patch + frag_off + kx * PITCH + cblk * 64;
+  const char* b_base = patch + frag_off + (KXB ? 0 : kx * PITCH) + cblk * 64;
 
   auto mfma_phase = [&]() {
-    // software pipeline over the 2 x 10 (pixel half, patch row) steps: the fragments of step s + 1 are requested before the
+    // software pipeline over the XH x 10 (pixel half, patch row) steps: the fragments of step s + 1 are requested before the
     // MFMAs of step s are issued (left alone the compiler orders it read, wait for everything, multiply)
-    half8_t a[2][TH];
-    half8_t bn = tr_frag(b_base), an = tr_frag(a_base);
+    constexpr int NST = K::XH * PH;
+    half8_t a[K::XH][TH];
+    half8_t bn = tr_frag<PITCH>(b_base), an = tr_frag<PITCH>(a_base);
 #pragma unroll
-    for (int st = 0; st < 2 * PH; ++st) {
+    for (int st = 0; st < NST; ++st) {
       const int xh = st / PH, pr = st % PH;
       const half8_t b = bn;
       if (pr < TH) a[xh][pr] = an;
-      if (st + 1 < 2 * PH) {
+      if (st + 1 < NST) {
         const int xh1 = (st + 1) / PH, pr1 = (st + 1) % PH;
-        bn = tr_frag(b_base + (pr1 * PW + xh1 * 16) * PITCH);
-        if (pr1 < TH) an = tr_frag(a_base + (pr1 * TW + xh1 * 16) * PITCH);
+        bn = tr_frag<PITCH>(b_base + (pr1 * PW + xh1 * 16) * PITCH);
+        if (pr1 < TH) an = tr_frag<PITCH>(a_base + (pr1 * TW + xh1 * 16) * PITCH);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the requests above the MFMAs: the wait before them then counts only the older reads
       // patch row pr feeds output row pr - ky through vertical tap ky
@@ -169,56 +196,66 @@ __global__ __launch_bounds__(NTH) void conv_patch_wgrad_k(const Params p) {
     mfma_phase();
   }
 
-  // ---- flush: a wave owns its (channel block, taps) outright -- no reduction across waves ----
-  float* slab = p.ws ? p.ws + (long long)blockIdx.x * p.ws_stride : nullptr;
+  // ---- flush: a wave owns its (channel blocks, taps) outright -- no reduction across waves ----
+  float* slab = p.ws ? p.ws + (long long)stream * p.ws_stride : nullptr;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = nblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int k = (ky * 3 + kx) * 64 + cblk * 32 + (lane & 31);
-      if (slab) slab[n * KTOT + k] = acc[ky][r];
-      else atomicAdd(p.dw + n * KTOT + k, acc[ky][r] * p.scale);
+      const int k = (ky * 3 + kx) * C + cblk * 32 + (lane & 31);
+      if (slab) slab[n * K::KTOT + k] = acc[ky][r];
+      else atomicAdd(p.dw + n * K::KTOT + k, acc[ky][r] * p.scale);
     }
+}
+
+template <int C, int TW, bool KXB>
+int launch(Params& p, const am_conv_geom* g, bool plan_only, hipStream_t s) {
+  using K = Cfg<C, TW, KXB>;
+  p.tiles_y = am_cdiv(g->IH, TH);
+  p.tiles_x = am_cdiv(g->IW, TW);
+  p.ntiles = g->B * p.tiles_y * p.tiles_x;
+  const int min_tiles = am_tuning(AM_TUNE_PATCH_WGRAD_MIN_TILES);
+  if (p.ntiles < min_tiles) return AM_ERR_UNSUPPORTED;  // below ~two tiles per CU the flush (one slab per stream) outweighs the single read
+  // tiles that overhang the image waste their MFMAs on it: at most 20 % unless the caller forces the kernel
+  if (min_tiles > 1 && (long long)g->IH * g->IW * 100 < (long long)p.tiles_y * TH * p.tiles_x * TW * 80) return AM_ERR_UNSUPPORTED;
+  // persistent: one workgroup per CU; KXB: three per tile stream, 80 streams (a multiple of 8: see the XCD note in the kernel)
+  const int cap = KXB ? 80 : 256;
+  p.streams = p.ntiles < cap ? p.ntiles : cap;
+  if (plan_only) return p.streams;
+  static bool attr_done_dev[AM_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[am_current_device()];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_wgrad_k<C, TW, KXB>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) != hipSuccess)
+      return AM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  g_am_conv_variant = AM_CV_WGRAD_PATCH_C64;
+  hipLaunchKernelGGL((conv_patch_wgrad_k<C, TW, KXB>), dim3(p.streams * (KXB ? 3 : 1)), dim3(K::NTH), K::LDS_BYTES, s, p);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
 }
 
 }  // namespace apw
 
 // Called by wgrad_dispatch (conv_gemm.hip).  plan_only: nothing is launched, the return value is the number of slabs (one per
-// workgroup) the slab form writes.  ws != NULL: slab form (unscaled partials at ws + b * ws_stride); else atomics into dw.
-// Returns AM_ERR_UNSUPPORTED unless the geometry is a dense 3x3 / stride 1 / pad 1 convolution with 64 input and output channels
-// (canonical tap order) large enough to fill the chip.
+// tile stream) the slab form writes.  ws != NULL: slab form (unscaled partials at ws + j * ws_stride); else atomics into dw.
+// Returns AM_ERR_UNSUPPORTED unless the geometry is a dense 3x3 / stride 1 / pad 1 convolution with 64 or 128 input and output
+// channels (canonical tap order) large enough to fill the chip.
 int am_conv_patch_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy, float scale, float* dw, float* ws, long long ws_stride,
                             bool plan_only, hipStream_t s) {
   using namespace apw;
-  if (g->ntaps != 9 || g->pix_shift != 31 || g->N != 64 || g->krun != 64 || g->osplit > 0) return AM_ERR_UNSUPPORTED;
+  if (g->ntaps != 9 || g->pix_shift != 31 || g->N != g->krun || (g->N != 64 && g->N != 128) || g->osplit > 0) return AM_ERR_UNSUPPORTED;
   if (g->iys != 1 || g->ixs != 1 || g->oys != 1 || g->oxs != 1 || g->oy0 != 0 || g->ox0 != 0) return AM_ERR_UNSUPPORTED;
   if (g->MH != g->IH || g->MW != g->IW || g->OH != g->IH || g->OW != g->IW) return AM_ERR_UNSUPPORTED;
-  if (g->ldi % 8 != 0 || g->x_coff % 8 != 0 || g->ldo % 8 != 0 || g->y_coff % 8 != 0 || g->ldi - g->x_coff < 64 || g->ldo - g->y_coff < 64)
+  if (g->ldi % 8 != 0 || g->x_coff % 8 != 0 || g->ldo % 8 != 0 || g->y_coff % 8 != 0 || g->ldi - g->x_coff < g->krun || g->ldo - g->y_coff < g->N)
     return AM_ERR_UNSUPPORTED;
   for (int t = 0; t < 9; ++t)
     if (g->dy[t] != t / 3 - 1 || g->dx[t] != t % 3 - 1) return AM_ERR_UNSUPPORTED;
   Params p;
-  p.tiles_y = am_cdiv(g->IH, TH);
-  p.tiles_x = am_cdiv(g->IW, TW);
-  p.ntiles = g->B * p.tiles_y * p.tiles_x;
-  const int min_tiles = am_tuning(AM_TUNE_PATCH_WGRAD_MIN_TILES);
-  if (p.ntiles < min_tiles) return AM_ERR_UNSUPPORTED;  // below ~two tiles per CU the flush (one slab per workgroup) outweighs the single read
-  // tiles that overhang the image waste their MFMAs on it: at most 20 % unless the caller forces the kernel
-  if (min_tiles > 1 && (long long)g->IH * g->IW * 100 < (long long)p.tiles_y * TH * p.tiles_x * TW * 80) return AM_ERR_UNSUPPORTED;
-  const int grid = p.ntiles < 256 ? p.ntiles : 256;  // persistent: one 12-wave workgroup per CU
-  if (plan_only) return grid;
   p.x = x; p.dy = dy; p.dw = dw; p.ws = ws; p.ws_stride = ws_stride; p.scale = scale;
   p.B = g->B; p.H = g->IH; p.W = g->IW; p.ldi = g->ldi; p.x_coff = g->x_coff; p.ldo = g->ldo; p.y_coff = g->y_coff;
-  static bool attr_done_dev[AM_MAX_DEVICES] = {};
-  bool& attr_done = attr_done_dev[am_current_device()];
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return AM_ERR_LAUNCH;
-    attr_done = true;
-  }
-  g_am_conv_variant = AM_CV_WGRAD_PATCH_C64;
-  hipLaunchKernelGGL(conv_patch_wgrad_k, dim3(grid), dim3(NTH), LDS_BYTES, s, p);
-  AM_CHECK_LAUNCH();
-  return AM_OK;
+  if (g->N == 64) return launch<64, 32, false>(p, g, plan_only, s);
+  if (am_tuning(AM_TUNE_PATCH_WGRAD_C128) == 0) return AM_ERR_UNSUPPORTED;
+  return launch<128, 16, true>(p, g, plan_only, s);
 }

@@ -935,42 +935,46 @@ def test_ring_kernel_generations_agree(case):
     assert rel_err(res[1][0][:1].permute(0, 3, 1, 2), yr) < 2e-3
 
 
-@pytest.mark.parametrize("shape", [(3, 45, 70), (2, 64, 96), (1, 8, 32), (5, 19, 33)])
-def test_patch_staged_weight_gradient_c64_vs_torch_and_generic_kernel(shape):
-    """conv_patch_wgrad_k (64 -> 64 channels, 3x3 / stride 1: dY tile and input patch staged once per 8x32-pixel tile, the whole
-    gradient in registers, one slab per workgroup) against torch's conv2d weight gradient and against the generic kernel on the
-    same operands, in the workspace form and in the atomic form, on maps with ragged tiles in both directions (a pixel outside
-    the map contributes nothing; the patch border is the zero padding) and with padded channel strides."""
+@pytest.mark.parametrize("case", [(64, 3, 45, 70), (64, 2, 64, 96), (64, 1, 8, 32), (64, 5, 19, 33),
+                                  (128, 2, 45, 40), (128, 1, 8, 16), (128, 3, 19, 33), (128, 11, 24, 48)])
+def test_patch_staged_weight_gradient_vs_torch_and_generic_kernel(case):
+    """conv_patch_wgrad_k (C -> C channels, C = 64 / 128, 3x3 / stride 1: dY tile and input patch staged once per tile, the whole
+    gradient in registers -- for C = 128 split over three workgroups, one per horizontal tap -- one slab per tile stream) against
+    torch's conv2d weight gradient and against the generic kernels on the same operands, in the workspace form and in the
+    atomic form, on maps with ragged tiles in both directions (a pixel outside the map contributes nothing; the patch border
+    is the zero padding), with fewer tiles than streams and with several tiles per stream (XCD-ordered walk)."""
     import ctypes
     from self_driving_model_amd.hip import conv as hc
-    B, H, W = shape
-    g = torch.Generator().manual_seed(B * 1000 + H)
-    x = torch.randn(B, 64, H, W, generator=g).half().float()
-    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).requires_grad_()
-    dyr = (torch.randn(B, 64, H, W, generator=g) * 0.5).half().float()
+    C, B, H, W = case
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    x = torch.randn(B, C, H, W, generator=g).half().float()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * np.sqrt(C))).requires_grad_()
+    dyr = (torch.randn(B, C, H, W, generator=g) * 0.5).half().float()
     (F.conv2d(x, w, None, stride=1, padding=1) * dyr).sum().backward()
-    spec = hc.ConvSpec(64, 64, 3, 1, 1)
-    xd, dyd = nhwc(x, torch.float16), nhwc(dyr, torch.float16, ld=64)
-    geom = hc.fwd_geom(spec, B, H, W, 64, 64, 2)
+    spec = hc.ConvSpec(C, C, 3, 1, 1)
+    xd, dyd = nhwc(x, torch.float16), nhwc(dyr, torch.float16, ld=C)
+    geom = hc.fwd_geom(spec, B, H, W, C, C, 2)
     L = hc._L()
-    wparam = torch.nn.Parameter(torch.zeros(64, 64, 3, 3, device=_dev()))
+    wparam = torch.nn.Parameter(torch.zeros(C, C, 3, 3, device=_dev()))
+    ntiles = B * ((H + 7) // 8) * ((W + 31) // 32 if C == 64 else (W + 15) // 16)
     res = {}
     old = L.am_get_tuning(6)
     try:
-        for name, min_tiles in (("conv_patch_wgrad_k", 1), ("conv_wgrad_k", 1 << 30)):
+        for name, min_tiles in (("patch", 1), ("generic", 1 << 30)):
+            kernels = "conv_patch_wgrad_k" if name == "patch" else ("conv_wgrad_k", "wgrad_ring_k")
             L.am_set_tuning(6, min_tiles)  # AM_TUNE_PATCH_WGRAD_MIN_TILES
             nbytes = ctypes.c_longlong(0)
             L.am_conv_wgrad_workspace_bytes(ctypes.byref(geom), hc.dt_code(torch.float16), ctypes.byref(nbytes))
-            if min_tiles == 1:  # one slab per workgroup = per tile up to 256
-                assert nbytes.value == min(256, B * ((H + 7) // 8) * ((W + 31) // 32)) * 64 * 576 * 4
+            if name == "patch":  # one slab per tile stream: 256 streams (C = 64), 80 streams of three workgroups (C = 128)
+                assert nbytes.value == min(256 if C == 64 else 80, ntiles) * C * 9 * C * 4
             a = hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec).clone()
-            launched_kernel(name, what=f"patch wgrad {shape}")
+            launched_kernel(kernels, what=f"patch wgrad {case}")
             b = hc.conv_wgrad_oihw(geom, xd, dyd, 0.5, wparam, spec).clone()
-            if min_tiles == 1:  # (the generic kernel's many pixel chunks meet in atomics: not reproducible bit for bit)
+            if name == "patch":  # (the generic kernel's many pixel chunks may meet in atomics: not reproducible bit for bit)
                 assert torch.equal(a, b), "the slab sum must be bitwise reproducible"
-            dwp = torch.zeros(64, 576, dtype=torch.float32, device=_dev())
+            dwp = torch.zeros(C, 9 * C, dtype=torch.float32, device=_dev())
             hc.conv_wgrad(geom, xd, dyd, 0.5, dwp)  # atomic form, packed layout
-            launched_kernel(name, what=f"patch wgrad atomic {shape}")
+            launched_kernel(kernels, what=f"patch wgrad atomic {case}")
             res[name] = (a, hc.unpack_wgrad(dwp, spec, torch.float16))
     finally:
         L.am_set_tuning(6, old)
@@ -980,7 +984,7 @@ def test_patch_staged_weight_gradient_c64_vs_torch_and_generic_kernel(shape):
         assert rel_err(ws_form, ref) < 2e-3, (name, rel_err(ws_form, ref))
         assert rel_err(atomic_form, ws_form) < 1e-5, (name, rel_err(atomic_form, ws_form))
     # same f16 products summed in fp32 in a different order
-    assert rel_err(res["conv_patch_wgrad_k"][0], res["conv_wgrad_k"][0]) < 1e-5
+    assert rel_err(res["patch"][0], res["generic"][0]) < 1e-5
 
 
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1, 4, 128, 160, torch.float16, "wgrad_ring_k"), (512, 512, 3, 1, 1, 6, 46, 80, torch.float16, "wgrad_ring_k"),
