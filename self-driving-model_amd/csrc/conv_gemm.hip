@@ -542,38 +542,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 // 16 when the slabs are many and the rows few (conv_patch_wgrad_k: 256 slabs x 64 rows -- twice the workgroups to hide the latency
 // of 64 dependent slab reads per wave; a part's reads are then 64-byte pieces)
 
-__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int Ktot, int krun,
+__global__ __launch_bounds__(1024) void wgrad_reduce_k(const float* __restrict__ ws, int nchunks, long long ws_stride, int Ktot, int krun,
                                                       int cin, int ntaps, float scale, float* __restrict__ out, int accumulate, int wr_ch) {
-  extern __shared__ float row[];  // [4 chunk groups][cpart * ntaps] in output order
+  extern __shared__ float row[];  // [blockDim / 64 chunk groups][cpart * ntaps] in output order
   const int n = blockIdx.y, c0 = blockIdx.x * wr_ch;
   const int cpart = min(wr_ch, cin - c0);
   const int nel = cpart * ntaps;
   const float* src = ws + (size_t)n * Ktot;
-  // wave w sums the chunks s = w, w + 4, ...: a wave-instruction reads 64 consecutive packed k of one slab (256 B), eight of
-  // them in flight per lane (a layer with few output channels has hundreds of short slabs: latency, not bytes, is its bound)
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // wave w of nwv sums the chunks s = w, w + nwv, ...: a wave-instruction reads 64 consecutive packed k of one slab (256 B), eight
+  // of them in flight per lane (a layer with few output channels has hundreds of short slabs: latency, not bytes, is its bound).
+  // nwv = blockDim.x / 64: 4 by default, 16 for the per-workgroup slabs of conv_patch_wgrad_k (80-256 of them: with 4 waves every
+  // lane ran 8 dependent rounds of loads, 25 us for 38 MB)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
   for (int i = lane; i < nel; i += 64) {
     const int t = i / cpart, c = i - t * cpart;
     const float* col = src + t * krun + c0 + c;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     int sidx = w;
-    for (; sidx + 28 < nchunks; sidx += 32) {
+    for (; sidx + 7 * nwv < nchunks; sidx += 8 * nwv) {
       a0 += col[(size_t)sidx * ws_stride];
-      a1 += col[(size_t)(sidx + 4) * ws_stride];
-      a2 += col[(size_t)(sidx + 8) * ws_stride];
-      a3 += col[(size_t)(sidx + 12) * ws_stride];
-      a4 += col[(size_t)(sidx + 16) * ws_stride];
-      a5 += col[(size_t)(sidx + 20) * ws_stride];
-      a6 += col[(size_t)(sidx + 24) * ws_stride];
-      a7 += col[(size_t)(sidx + 28) * ws_stride];
+      a1 += col[(size_t)(sidx + nwv) * ws_stride];
+      a2 += col[(size_t)(sidx + 2 * nwv) * ws_stride];
+      a3 += col[(size_t)(sidx + 3 * nwv) * ws_stride];
+      a4 += col[(size_t)(sidx + 4 * nwv) * ws_stride];
+      a5 += col[(size_t)(sidx + 5 * nwv) * ws_stride];
+      a6 += col[(size_t)(sidx + 6 * nwv) * ws_stride];
+      a7 += col[(size_t)(sidx + 7 * nwv) * ws_stride];
     }
-    for (; sidx < nchunks; sidx += 4) a0 += col[(size_t)sidx * ws_stride];
+    for (; sidx < nchunks; sidx += nwv) a0 += col[(size_t)sidx * ws_stride];
     row[w * nel + c * ntaps + t] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   }
   __syncthreads();
   float* o = out + ((size_t)n * cin + c0) * ntaps;
   for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-    const float v = ((row[i] + row[nel + i]) + (row[2 * nel + i] + row[3 * nel + i])) * scale;
+    float v = (row[i] + row[nel + i]) + (row[2 * nel + i] + row[3 * nel + i]);
+    for (int g = 4; g < nwv; g += 4) v += (row[g * nel + i] + row[(g + 1) * nel + i]) + (row[(g + 2) * nel + i] + row[(g + 3) * nel + i]);
+    v *= scale;
     o[i] = accumulate ? o[i] + v : v;
   }
 }
@@ -787,8 +791,9 @@ extern "C" int am_conv_wgrad_ws(const am_conv_geom* g, int dtype, const void* x,
   if (rc != AM_OK) return rc;
   const int wr_ch = own ? 16 : 32;
   const int parts = am_cdiv(cin, wr_ch);
-  const size_t lds = 4 * (size_t)(cin < wr_ch ? cin : wr_ch) * g->ntaps * sizeof(float);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(parts, g->N), dim3(256), lds, s, ws, slabs, stride, (int)Ktot, g->krun, cin, g->ntaps, scale,
+  const int nwv = own ? 16 : 4;
+  const size_t lds = nwv * (size_t)(cin < wr_ch ? cin : wr_ch) * g->ntaps * sizeof(float);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(parts, g->N), dim3(nwv * 64), lds, s, ws, slabs, stride, (int)Ktot, g->krun, cin, g->ntaps, scale,
                      dw_oihw, accumulate, wr_ch);
   AM_CHECK_LAUNCH();
   return AM_OK;
