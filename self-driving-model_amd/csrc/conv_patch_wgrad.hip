@@ -8,7 +8,7 @@
 // workgroup walks 8x32-pixel output tiles, stages each tile's dY block and its 10x34 input patch ONCE in LDS (pixel-major,
 // pitch 192 B = 64 mod 128: both MFMA operands come out of the ds_read_b64_tr_b16 transposing read) and keeps the whole
 // gradient in registers: twelve waves = 2 output-channel blocks x 3 horizontal taps x 2 input-channel blocks, each with the
-// three vertical taps of its column (3 accumulators of 32x32).  A wave walks the patch rows once: the row's fragment feeds
+// three vertical taps of its column (3 accumulators of 32x32; as v_mfma_f32_16x16x32_f16 over whole 32-pixel rows: see M16).  A wave walks the patch rows once: the row's fragment feeds
 // the three taps (output rows r, r-1, r-2), so an MFMA costs 0.75 KB of LDS reads.  The next tile's global loads are issued
 // before the MFMA phase and land under it.  One flush per workgroup: plain stores into its slab of the caller's workspace
 // (am_conv_wgrad_ws; wgrad_reduce_k sums the slabs) or, without a workspace, fp32 atomics.
@@ -69,8 +69,11 @@ struct Cfg {
   static_assert(NTH % CPP == 0 && PITCH % 128 == 64 && TW % 16 == 0 && NTH <= 1024, "");
 };
 
-template <int C, int TW, bool KXB>
+// M16: v_mfma_f32_16x16x32_f16 with a whole 32-pixel tile row as the k of one MFMA (TW = 32 only) instead of 32x32x16 over half rows:
+// the same fragment bytes and MFMA cycles, less power per FLOP (scratch/mfma_probe: +13 % sustained under the power limit)
+template <int C, int TW, bool KXB, bool M16>
 __global__ __launch_bounds__((Cfg<C, TW, KXB>::NTH)) void conv_patch_wgrad_k(const Params p) {
+  static_assert(!M16 || TW == 32, "M16: one MFMA spans a 32-pixel tile row");
   using K = Cfg<C, TW, KXB>;
   constexpr int NTH = K::NTH, PW = K::PW, PITCH = K::PITCH, CPP = K::CPP, PCH = K::PCH, DCH = K::DCH, CB = K::CB;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -85,11 +88,21 @@ __global__ __launch_bounds__((Cfg<C, TW, KXB>::NTH)) void conv_patch_wgrad_k(con
   const int kx = KXB ? (int)blockIdx.x / p.streams : wid / (CB * CB);
   const int stream = KXB ? (int)blockIdx.x % p.streams : (int)blockIdx.x;
 
-  f32x16 acc[3];
+  f32x16 acc[M16 ? 1 : 3];      // 32x32x16: [ky]
+  f32x4 acc4[M16 ? 3 : 1][2][2];  // 16x16x32: [ky][16-channel half of the output block][16-channel half of the input block]
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc4[i][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
 
   // which patch pixel / dY pixel and 16-byte piece a thread fetches never changes: (row << 8 | column) per chunk
   int ppos[PCH];
@@ -160,6 +173,40 @@ __global__ __launch_bounds__((Cfg<C, TW, KXB>::NTH)) void conv_patch_wgrad_k(con
   const char* a_base = dYs + frag_off + nblk * 64;
   const char* b_base = patch + frag_off + (KXB ? 0 : kx * PITCH) + cblk * 64;
 
+  // M16 fragments: lane = 16 channels (i16) x 4 pixel groups (gq): pixel 8 * gq + q, channels 4 * pp ..+3 of a 16-channel half
+  const int frag16_off = (8 * gq + q) * PITCH + 4 * pp * 2;
+  auto mfma_phase16 = [&]() {
+    const char* a16 = dYs + frag16_off + nblk * 64;
+    const char* b16 = patch + frag16_off + (KXB ? 0 : kx * PITCH) + cblk * 64;
+    half8_t a[TH][2];
+    half8_t bn[2] = {tr_frag<PITCH>(b16), tr_frag<PITCH>(b16 + 32)}, an[2] = {tr_frag<PITCH>(a16), tr_frag<PITCH>(a16 + 32)};
+#pragma unroll
+    for (int pr = 0; pr < PH; ++pr) {
+      const half8_t b0 = bn[0], b1 = bn[1];
+      if (pr < TH) { a[pr][0] = an[0]; a[pr][1] = an[1]; }
+      if (pr + 1 < PH) {
+        bn[0] = tr_frag<PITCH>(b16 + (pr + 1) * PW * PITCH);
+        bn[1] = tr_frag<PITCH>(b16 + (pr + 1) * PW * PITCH + 32);
+        if (pr + 1 < TH) {
+          an[0] = tr_frag<PITCH>(a16 + (pr + 1) * TW * PITCH);
+          an[1] = tr_frag<PITCH>(a16 + (pr + 1) * TW * PITCH + 32);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int r = pr - ky;
+        if (r >= 0 && r < TH) {
+#pragma unroll
+          for (int ns = 0; ns < 2; ++ns) {
+            acc4[ky][ns][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][ns], b0, acc4[ky][ns][0], 0, 0, 0);
+            acc4[ky][ns][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][ns], b1, acc4[ky][ns][1], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto mfma_phase = [&]() {
     // software pipeline over the XH x 10 (pixel half, patch row) steps: the fragments of step s + 1 are requested before the
     // MFMAs of step s are issued (left alone the compiler orders it read, wait for everything, multiply)
@@ -193,23 +240,39 @@ __global__ __launch_bounds__((Cfg<C, TW, KXB>::NTH)) void conv_patch_wgrad_k(con
     store_tile(rpA, rdA);
     __syncthreads();
     if (tile + tstep < tend) load_tile(tile + tstep, rpA, rdA);  // in flight during the MFMA phase
-    mfma_phase();
+    if constexpr (M16) mfma_phase16(); else mfma_phase();
   }
 
   // ---- flush: a wave owns its (channel blocks, taps) outright -- no reduction across waves ----
   float* slab = p.ws ? p.ws + (long long)stream * p.ws_stride : nullptr;
+  if constexpr (M16) {
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = nblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int k = (ky * 3 + kx) * C + cblk * 32 + (lane & 31);
-      if (slab) slab[n * K::KTOT + k] = acc[ky][r];
-      else atomicAdd(p.dw + n * K::KTOT + k, acc[ky][r] * p.scale);
-    }
+      for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = nblk * 32 + ns * 16 + 4 * (lane >> 4) + j;
+            const int k = (ky * 3 + kx) * C + cblk * 32 + cs * 16 + (lane & 15);
+            if (slab) slab[n * K::KTOT + k] = acc4[ky][ns][cs][j];
+            else atomicAdd(p.dw + n * K::KTOT + k, acc4[ky][ns][cs][j] * p.scale);
+          }
+  } else {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int k = (ky * 3 + kx) * C + cblk * 32 + (lane & 31);
+        if (slab) slab[n * K::KTOT + k] = acc[ky][r];
+        else atomicAdd(p.dw + n * K::KTOT + k, acc[ky][r] * p.scale);
+      }
+  }
 }
 
-template <int C, int TW, bool KXB>
+template <int C, int TW, bool KXB, bool M16>
 int launch(Params& p, const am_conv_geom* g, bool plan_only, hipStream_t s) {
   using K = Cfg<C, TW, KXB>;
   p.tiles_y = am_cdiv(g->IH, TH);
@@ -226,12 +289,12 @@ int launch(Params& p, const am_conv_geom* g, bool plan_only, hipStream_t s) {
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_wgrad_k<C, TW, KXB>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_wgrad_k<C, TW, KXB, M16>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   g_am_conv_variant = AM_CV_WGRAD_PATCH_C64;
-  hipLaunchKernelGGL((conv_patch_wgrad_k<C, TW, KXB>), dim3(p.streams * (KXB ? 3 : 1)), dim3(K::NTH), K::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((conv_patch_wgrad_k<C, TW, KXB, M16>), dim3(p.streams * (KXB ? 3 : 1)), dim3(K::NTH), K::LDS_BYTES, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -255,7 +318,7 @@ int am_conv_patch_wgrad_f16(const am_conv_geom* g, const void* x, const void* dy
   Params p;
   p.x = x; p.dy = dy; p.dw = dw; p.ws = ws; p.ws_stride = ws_stride; p.scale = scale;
   p.B = g->B; p.H = g->IH; p.W = g->IW; p.ldi = g->ldi; p.x_coff = g->x_coff; p.ldo = g->ldo; p.y_coff = g->y_coff;
-  if (g->N == 64) return launch<64, 32, false>(p, g, plan_only, s);
+  if (g->N == 64) return launch<64, 32, false, true>(p, g, plan_only, s);  // (32x32x16 on the same tiles: 145 us against 139 at B = 32)
   if (am_tuning(AM_TUNE_PATCH_WGRAD_C128) == 0) return AM_ERR_UNSUPPORTED;
-  return launch<128, 16, true>(p, g, plan_only, s);
+  return launch<128, 16, true, false>(p, g, plan_only, s);
 }
