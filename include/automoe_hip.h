@@ -141,7 +141,9 @@ int am_conv_last_variant(void);
  *                          (conv_patch_wgrad_k) from this many 8x32-pixel tiles on (default 512; a huge value: never); the same
  *                          bound, in 8x16-pixel tiles, for the 128 -> 128 channel form.
  *   AM_TUNE_PATCH_WGRAD_C128 1 (default): 128 -> 128 channel 3x3 / stride-1 layers take conv_patch_wgrad_k<128> (three workgroups
- *                          per tile stream, one per horizontal tap), 0: wgrad_ring_k. */
+ *                          per tile stream, one per horizontal tap), 0: wgrad_ring_k.
+ *   AM_TUNE_DUO_MFMA16     conv3x3_c64n64_duo_k with v_mfma_f32_16x16x32_f16 and a 160-byte patch pitch (1) or with
+ *                          v_mfma_f32_32x32x16_f16 and a 144-byte pitch (0). */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
@@ -150,7 +152,8 @@ int am_conv_last_variant(void);
 #define AM_TUNE_HALO_MIN_TILES 5
 #define AM_TUNE_PATCH_WGRAD_MIN_TILES 6
 #define AM_TUNE_PATCH_WGRAD_C128 7
-#define AM_TUNE_COUNT 8
+#define AM_TUNE_DUO_MFMA16 8
+#define AM_TUNE_COUNT 9
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 

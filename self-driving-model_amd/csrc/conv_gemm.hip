@@ -634,6 +634,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_HALO_MIN_TILES */ 256,
     /* AM_TUNE_PATCH_WGRAD_MIN_TILES */ 512,
     /* AM_TUNE_PATCH_WGRAD_C128 */ 1,
+    /* AM_TUNE_DUO_MFMA16 */ 1,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }

@@ -22,18 +22,28 @@ namespace amp3 {
 
 constexpr int TH = 8, TW = 16;             // output tile of one group
 constexpr int PH = TH + 2, PW = TW + 2;    // input patch
-constexpr int PP = 144;                    // LDS bytes per patch pixel (9 chunks of 16 B, the last one padding)
 constexpr int NPIX = PH * PW;              // 180
-constexpr int NINST = (NPIX * 9 + 63) / 64;   // 26 wave-instructions of 64 x 16 B
-constexpr int PATCH_SLOT = NINST * 1024;      // 26624
-constexpr int IPW = (NINST + 3) / 4;          // instructions per wave of a group (7; the last ones are skipped)
 constexpr int WROW = 1152;                    // bytes per packed weight row (576 halves)
 constexpr int SP = 80;                        // staging pitch per output pixel: 32 channels x 2 B + 16 B pad
 constexpr int STG_WAVE = 64 * SP;             // 5120
-constexpr int PATCH_BYTES = 2 * PATCH_SLOT;   // double buffer
-constexpr int LDS_BYTES = PATCH_BYTES + 4 * STG_WAVE + 1024;  // 74752: two workgroups per CU
+// M16 = false: v_mfma_f32_32x32x16_f16, patch pixels at a 144-byte LDS pitch (9 chunks of 16 B, the last one padding).
+// M16 = true:  v_mfma_f32_16x16x32_f16 (less power per FLOP: the launch is power-limited), a pixel fragment is one 16-pixel
+//              tile row and 32 channels; its ds_read_b128 is conflict free at a 160-byte pitch (10 chunks, two of padding: a
+//              16-lane service group {0-3,12-15 | k-quarter q} + {4-11 | k-quarter q+1} then covers the 16 bank quads exactly once,
+//              at 144 bytes it does not for any pixel order).
+template <bool M16>
+struct Lay {
+  static constexpr int CPP = M16 ? 10 : 9;                 // 16-byte chunks per patch pixel
+  static constexpr int PP = CPP * 16;                      // LDS bytes per patch pixel
+  static constexpr int NINST = (NPIX * CPP + 63) / 64;     // wave-instructions of 64 x 16 B (26 / 29)
+  static constexpr int PATCH_SLOT = NINST * 1024;
+  static constexpr int IPW = (NINST + 3) / 4;              // instructions per wave of a group (the last ones are skipped)
+  static constexpr int PATCH_BYTES = 2 * PATCH_SLOT;       // double buffer
+  static constexpr int LDS_BYTES = PATCH_BYTES + 4 * STG_WAVE + 1024;  // 74,752 / 80,896: two workgroups per CU
+  static_assert(64 * WROW <= PATCH_BYTES + 4 * STG_WAVE, "weights pass through the patch + staging area once");
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
 constexpr unsigned OOB = 0xC0000000u;         // + any tile base stays above num_records (< 2^30)
-static_assert(64 * WROW <= PATCH_BYTES + 4 * STG_WAVE, "weights pass through the patch + staging area once");
 
 struct Patch3Params {
   const void* x;
@@ -83,8 +93,10 @@ __device__ __forceinline__ void buffer_store16_asm(rsrc_words_t v, rsrc_words_t 
 // full 64-byte half rows) at the START of the tile, lands under the MFMA phase, and is added to the f16-rounded conv + bias
 // with a packed f16 add (= the fp32 add of two f16 values rounded once), the same two roundings as conv -> f16 -> normalise pass.
 
-template <bool EPI>
+template <bool EPI, bool M16>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Params p) {
+  using L = Lay<M16>;
+  constexpr int PP = L::PP, CPP = L::CPP, NINST = L::NINST, PATCH_SLOT = L::PATCH_SLOT, IPW = L::IPW, PATCH_BYTES = L::PATCH_BYTES;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   rsrc_words_t yr;
   {
@@ -102,16 +114,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): at the 144-byte pitch a group is conflict free iff its 16 patch pixels
   // differ mod 16, and the second fragment row starts 18 = 2 (mod 16) pixels later -- so row 1 is rotated by two columns.
   const int frow = rx >> 4, fcol = rx < 16 ? rx : (rx + 14) & 15;
+  const int c16 = lane & 15, kq = lane >> 4;  // M16: pixel column of the lane inside a 16-pixel row fragment, k quarter (8 channels)
 
   // ---- weights: global -> LDS (coalesced, once) -> registers.  wf[tap*4 + ks] = A fragment (row = channel tn*32 + rx,
   // k chunk 2*ks + kg) ----
   for (int inst = wid; inst < 64 * WROW / 1024; inst += 4) buffer_to_lds16(p.w, p.w_bytes, smem + inst * 1024, (unsigned)(inst * 1024 + lane * 16));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // M16: wf[(tap*2 + k32 step)*2 + ca] = A fragment (row = channel tn*32 + ca*16 + c16, 8 channels of k quarter kq)
   half8_t wf[36];
 #pragma unroll
-  for (int s = 0; s < 36; ++s)
-    wf[s] = *reinterpret_cast<const half8_t*>(smem + (tn * 32 + rx) * WROW + (s >> 2) * 128 + (s & 3) * 32 + kg * 16);
+  for (int s = 0; s < 36; ++s) {
+    if constexpr (M16) wf[s] = *reinterpret_cast<const half8_t*>(smem + (tn * 32 + (s & 1) * 16 + c16) * WROW + (s >> 2) * 128 + ((s >> 1) & 1) * 64 + kq * 16);
+    else wf[s] = *reinterpret_cast<const half8_t*>(smem + (tn * 32 + rx) * WROW + (s >> 2) * 128 + (s & 3) * 32 + kg * 16);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // everyone holds its fragments: the patch area may be overwritten
 
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
     const unsigned tb = (unsigned)((((img * p.H + iy0) * p.W + ix0) * p.ldi + p.x_coff) * 2);  // wraps for the halo row/col: fine
     char* dst = gpatch + buf * PATCH_SLOT + w4 * (IPW * 1024);
-    // LDS position q = (w4*IPW + i)*64 + lane -> patch pixel q/9, 16-byte chunk q%9 (chunk 8 = pad).  Recomputed per tile
+    // LDS position q = (w4*IPW + i)*64 + lane -> patch pixel q/CPP, 16-byte chunk q%CPP (chunks >= 8 = pad).  Recomputed per tile
     // from an opaque copy of the lane id: values hipcc hoists out of the tile loop end up spilled, and a spill reload
     // next to the LDS-DMA costs an s_waitcnt vmcnt(0).
     int ln = lane;
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     for (int i = 0; i < IPW; ++i) {
       if (w4 * IPW + i < NINST) {
         const int q = (w4 * IPW + i) * 64 + ln;
-        const int pix = q / 9, cc = q - pix * 9;
+        const int pix = q / CPP, cc = q - pix * CPP;
         const int prow = pix / PW, pcol = pix - prow * PW;
         const bool ok = cc < 8 && pix < NPIX && (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pcol) < (unsigned)p.W;
         const unsigned vo = ok ? tb + (unsigned)(prow * row_bytes + pcol * pix_bytes + cc * 16) : OOB;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     for (int i = 0; i < IPW; ++i) {
       if (w4 * IPW + i < NINST) {
         const int q = (w4 * IPW + i) * 64 + ln;
-        const int pix = q / 9, cc = q - pix * 9;
+        const int pix = q / CPP, cc = q - pix * CPP;
         const int prow = pix / PW, pcol = pix - prow * PW;
         if (cc < 8 && pix < NPIX && (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pcol) < (unsigned)p.W) {
           half8_t* slot = reinterpret_cast<half8_t*>(dst + i * 1024 + ln * 16);
@@ -183,17 +199,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   };
 
   // per-lane partial BN sums of the lane's 16 channels, folded across pixel lanes at the end (EPI: the lane's 16 bias values)
+  // (M16: the lane's 8 channels are tn*32 + ca*16 + 4*kq + j -- registers r = ca*4 + j of the same vectors, the rest unused)
   f32x16 ssum, ssq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    ssum[r] = (EPI && p.bias != nullptr) ? p.bias[tn * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] : 0.f;
+    const int ch = M16 ? tn * 32 + ((r >> 2) & 1) * 16 + 4 * kq + (r & 3) : tn * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+    ssum[r] = (EPI && p.bias != nullptr) ? p.bias[ch] : 0.f;
     ssq[r] = 0.f;
   }
   const bool has_res = EPI && p.res != nullptr;
   const bool relu_late = EPI && p.relu && has_res, relu_early = EPI && p.relu && !has_res;
 
   // fragment origin of this lane inside a patch: pixel fragment tm covers rows hsel*4 + tm*2 + frow, cols fcol
-  const int fbase = ((hsel * 4 + frow) * PW + fcol) * PP + kg * 16;
+  const int fbase = M16 ? ((hsel * 4) * PW + c16) * PP + kq * 16 : ((hsel * 4 + frow) * PW + fcol) * PP + kg * 16;
   char* stg = smem + PATCH_BYTES + wid * STG_WAVE;
 
   // Tile stream of this workgroup.  Workgroups are dispatched round-robin over the 8 XCDs (id & 7) and each XCD has its
@@ -224,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const char* pt = gpatch + buf * PATCH_SLOT + fbase;
     f32x16 acc[2];  // [tm]
     half8_t fp[2][2];
+    f32x4 acc4[4][2];  // M16: [pixel row pb][16-channel half ca]
+    half8_t fq[2][4];  // M16: [parity][pb]
     rsrc_words_t resv[4];
     if (EPI && has_res) {  // the store loop's pieces of the residual tile: in flight under the MFMA phase
       const int img = tile / tiles_per_img;
@@ -238,29 +258,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
         resv[it] = buffer_load16(p.res, p.y_bytes, vo);
       }
     }
+    if constexpr (M16) {
+      // 18 k32 steps (tap-major, two per tap): the four pixel-row fragments of step s+1 are requested before the eight MFMAs of step s
 #pragma unroll
-    for (int s = 0; s < 36 + 1; ++s) {
-      if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments (issued one MFMA pair ago)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < 36) {
-        const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
+      for (int s = 0; s < 18 + 1; ++s) {
+        if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 18) {
+          const int tap = s >> 1, ks2 = s & 1, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-          fp[s & 1][tm] = *reinterpret_cast<const half8_t*>(pt + ((tm * 2 + kh) * PW + kw) * PP + ks * 32);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s >= 1) {
-        const int c = (s - 1) & 1;
-        if (s == 1) {  // first step starts from the constant zero: no accumulator clears
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], fp[c][tm], z, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s - 1], fp[c][tm], acc[tm], 0, 0, 0);
+          for (int pb = 0; pb < 4; ++pb)
+            fq[s & 1][pb] = *reinterpret_cast<const half8_t*>(pt + ((pb + kh) * PW + kw) * PP + ks2 * 64);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s >= 1) {
+          const int c = (s - 1) & 1;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int ca = 0; ca < 2; ++ca)
+              acc4[pb][ca] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(s - 1) * 2 + ca], fq[c][pb], s == 1 ? z : acc4[pb][ca], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 36 + 1; ++s) {
+        if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments (issued one MFMA pair ago)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 36) {
+          const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
+  #pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            fp[s & 1][tm] = *reinterpret_cast<const half8_t*>(pt + ((tm * 2 + kh) * PW + kw) * PP + ks * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s >= 1) {
+          const int c = (s - 1) & 1;
+          if (s == 1) {  // first step starts from the constant zero: no accumulator clears
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], fp[c][tm], z, 0, 0, 0);
+          } else {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s - 1], fp[c][tm], acc[tm], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  
     }
 
     // This wave's share of the next patch (issued a whole epilogue + MFMA phase ago) and the previous tile's stores are
@@ -282,36 +329,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    if (!EPI && (ty * TH + TH > p.H || tx * TW + TW > p.W)) {
-      // edge tile: pixels outside the image are not conv outputs -- zero them so they stay out of the statistics
+    if constexpr (M16) {
+      // acc4[pb][ca][j] = out(pixel (row hsel*4 + pb, col c16), channel tn*32 + ca*16 + 4*kq + j); ssum / ssq registers ca*4 + j
+      if (!EPI && (ty * TH + TH > p.H || tx * TW + TW > p.W)) {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const bool ok = ty * TH + hsel * 4 + tm * 2 + frow < p.H && tx * TW + fcol < p.W;
+        for (int pb = 0; pb < 4; ++pb) {
+          const bool ok = ty * TH + hsel * 4 + pb < p.H && tx * TW + c16 < p.W;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][r] = ok ? acc[tm][r] : 0.f;
+          for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[pb][ca][j] = ok ? acc4[pb][ca][j] : 0.f;
+        }
       }
-    }
-    if (EPI) {  // ssum holds the bias
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        acc[tm] += ssum;
-        if (relu_early) acc[tm] = __builtin_elementwise_max(acc[tm], ssq);  // (ssq stays zero)
-      }
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (EPI) {  // ssum holds the bias
+              acc4[pb][ca][j] += ssum[ca * 4 + j];
+              if (relu_early) acc4[pb][ca][j] = fmaxf(acc4[pb][ca][j], 0.f);
+            } else {
+              ssum[ca * 4 + j] += acc4[pb][ca][j];
+              ssq[ca * 4 + j] = __builtin_fmaf(acc4[pb][ca][j], acc4[pb][ca][j], ssq[ca * 4 + j]);
+            }
+          }
+      // stage 64 pixels x 32 channels in this wave's own area (pixel pb*16 + c16: the store loop's row / column split)
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca)
+          *reinterpret_cast<half4_t*>(stg + (pb * 16 + c16) * SP + (ca * 16 + 4 * kq) * 2) = __builtin_convertvector(acc4[pb][ca], half4_t);
     } else {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        ssum += acc[tm];
-        ssq = __builtin_elementwise_fma(acc[tm], acc[tm], ssq);
+    if (!EPI && (ty * TH + TH > p.H || tx * TW + TW > p.W)) {
+        // edge tile: pixels outside the image are not conv outputs -- zero them so they stay out of the statistics
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const bool ok = ty * TH + hsel * 4 + tm * 2 + frow < p.H && tx * TW + fcol < p.W;
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tm][r] = ok ? acc[tm][r] : 0.f;
+        }
       }
+      if (EPI) {  // ssum holds the bias
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          acc[tm] += ssum;
+          if (relu_early) acc[tm] = __builtin_elementwise_max(acc[tm], ssq);  // (ssq stays zero)
+        }
+      } else {
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          ssum += acc[tm];
+          ssq = __builtin_elementwise_fma(acc[tm], acc[tm], ssq);
+        }
+      }
+      // stage 64 pixels x 32 channels in this wave's own area, then 64-byte half-rows go out with 16-byte stores
+  #pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+          const f32x4 v = {acc[tm][4 * jq], acc[tm][4 * jq + 1], acc[tm][4 * jq + 2], acc[tm][4 * jq + 3]};
+          *reinterpret_cast<half4_t*>(stg + (tm * 32 + frow * 16 + fcol) * SP + (8 * jq + 4 * kg) * 2) = __builtin_convertvector(v, half4_t);
+        }
     }
-    // stage 64 pixels x 32 channels in this wave's own area, then 64-byte half-rows go out with 16-byte stores
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int jq = 0; jq < 4; ++jq) {
-        const f32x4 v = {acc[tm][4 * jq], acc[tm][4 * jq + 1], acc[tm][4 * jq + 2], acc[tm][4 * jq + 3]};
-        *reinterpret_cast<half4_t*>(stg + (tm * 32 + frow * 16 + fcol) * SP + (8 * jq + 4 * kg) * 2) = __builtin_convertvector(v, half4_t);
-      }
     // the wave reads back what its own lanes wrote (LDS executes a wave's accesses in order); the asm also keeps the
     // compiler from moving the differently typed reads above the writes
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -339,15 +420,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < (M16 ? 8 : 16); ++r) {
       float sv = ssum[r], qv = ssq[r];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
+      for (int o = (M16 ? 8 : 16); o > 0; o >>= 1) {  // over the lanes that share the channels: 16 pixel columns / 32 pixels
         sv += __shfl_xor(sv, o, 64);
         qv += __shfl_xor(qv, o, 64);
       }
-      if (rx == 0) {
-        const int ch = 8 * (r >> 2) + 4 * kg + (r & 3);
+      if (M16 ? c16 == 0 : rx == 0) {
+        const int ch = M16 ? (r >> 2) * 16 + 4 * kq + (r & 3) : 8 * (r >> 2) + 4 * kg + (r & 3);
         part[(wid * 32 + ch) * 2 + 0] = sv;
         part[(wid * 32 + ch) * 2 + 1] = qv;
       }
@@ -408,17 +489,25 @@ int am_conv3x3_c64n64_duo_pre_f16(const am_conv_geom* g, const void* x, const fl
   p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.y_bytes = (unsigned)y_bytes;
   p.bias = bias; p.res = res; p.relu = relu;
-  static bool attr_done_dev[AM_MAX_DEVICES][2] = {};
-  bool& attr_done = attr_done_dev[am_current_device()][epi ? 1 : 0];
+  const bool m16 = am_tuning(AM_TUNE_DUO_MFMA16) != 0;
+  const int lds = m16 ? Lay<true>::LDS_BYTES : Lay<false>::LDS_BYTES;
+  static bool attr_done_dev[AM_MAX_DEVICES][4] = {};
+  bool& attr_done = attr_done_dev[am_current_device()][(epi ? 1 : 0) + (m16 ? 2 : 0)];
   if (!attr_done) {
-    const void* fn = epi ? reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<true>) : reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return AM_ERR_LAUNCH;
+    const void* fn = m16 ? (epi ? reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<true, true>) : reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<false, true>))
+                         : (epi ? reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<true, false>) : reinterpret_cast<const void*>(conv3x3_c64n64_duo_k<false, false>));
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AM_ERR_LAUNCH;
     attr_done = true;
   }
   const int grid = p.ntiles < 512 ? ((p.ntiles + 7) & ~7) : 512;  // two persistent workgroups per CU, a multiple of the 8 XCDs
   g_am_conv_variant = AM_CV_DUO_C64;
-  if (epi) hipLaunchKernelGGL(conv3x3_c64n64_duo_k<true>, dim3(grid), dim3(256), LDS_BYTES, s, p);
-  else hipLaunchKernelGGL(conv3x3_c64n64_duo_k<false>, dim3(grid), dim3(256), LDS_BYTES, s, p);
+  if (m16) {
+    if (epi) hipLaunchKernelGGL((conv3x3_c64n64_duo_k<true, true>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv3x3_c64n64_duo_k<false, true>), dim3(grid), dim3(256), lds, s, p);
+  } else {
+    if (epi) hipLaunchKernelGGL((conv3x3_c64n64_duo_k<true, false>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv3x3_c64n64_duo_k<false, false>), dim3(grid), dim3(256), lds, s, p);
+  }
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
