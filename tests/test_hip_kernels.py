@@ -453,11 +453,15 @@ WS_KERNEL = {(2, 180, 320): "conv3x3_c64n64_duo_k", (1, 200, 333): "conv3x3_c64n
              (3, 45, 64): "conv_gemm2_k"}  # the small problem stays below the weights-in-registers kernel's size gate
 
 
+@pytest.mark.parametrize("mfma16", [1, 0])
 @pytest.mark.parametrize("shape", [(2, 180, 320), (3, 45, 64), (1, 200, 333)])
-def test_conv3x3_weights_stationary_kernel_vs_torch(shape):
-    """The 64->64 3x3 patch kernel (conv_patch.hip) takes over from the gather-GEMM for large fp16 problems: same
-    results, including BatchNorm statistics that must exclude the out-of-image rows of edge tiles."""
+def test_conv3x3_weights_stationary_kernel_vs_torch(shape, mfma16, request):
+    """The 64->64 3x3 weights-in-registers kernel (conv_patch3.hip) takes over from the gather-GEMM for large fp16 problems: same
+    results, including BatchNorm statistics that must exclude the out-of-image rows of edge tiles; in both of its MFMA forms
+    (AM_TUNE_DUO_MFMA16: 16x16x32 over 16-pixel row fragments at a 160-byte patch pitch -- the default -- and 32x32x16 at 144)."""
     from self_driving_model_amd.hip import conv as hc
+    old_form = hc._L().am_set_tuning(8, mfma16)
+    request.addfinalizer(lambda: hc._L().am_set_tuning(8, old_form))
     B, H, W = shape
     g = torch.Generator().manual_seed(H)
     x = torch.randn(B, 64, H, W, generator=g).half().float()
