@@ -131,7 +131,8 @@ int am_conv_last_variant(void);
  *   AM_TUNE_RING   0: conv_ring_k (v_mfma_f32_32x32x16_f16), 1: conv_ring16_k (16x16x32, transposed product, pieces issued as a
  *                  block), 2 (default): the same with static issue priority for waves 4-7, 3: pieces placed by wave age.
  *   AM_TUNE_RING128_MIN_TILES   fewest 256x128 tiles (M/256 * N/128) for which conv_ring_k<256,128> is dispatched.
- *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 0: always the register-staged conv_wgrad_k.
+ *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 2: the same with v_mfma_f32_16x16x32_f16 on its
+ *                  256-channel tile (measured: no gain per step), 0: always the register-staged conv_wgrad_k.
  *   AM_TUNE_WGRAD_MAX_SLABS   am_conv_wgrad_ws keeps one slab per pixel chunk up to this many chunks; beyond it the chunks add
  *                  atomically into ONE zero-filled slab (0: always; a huge value: never).
  *   AM_TUNE_RING_SHORT_K   contractions of at most this many 32-element K-steps take the 256x128 ring tile even when N >= 256;

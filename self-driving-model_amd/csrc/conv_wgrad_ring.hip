@@ -52,8 +52,12 @@ __device__ __forceinline__ half8_t read_tr(const char* lo_addr, const char* hi_a
   return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
 }
 
-template <int TM>
+// M16 (TM = 4 only): v_mfma_f32_16x16x32_f16 -- one MFMA spans the 32 pixels of a step (less power per FLOP on this power-limited part:
+// DESIGN.md); a fragment is 16 channels x 32 pixels, lane group gq = pixel octet.  Pieces 8-15 of a stage sit 32 bytes further: the octets
+// gq and gq + 1 of one 32-lane service group of the transposing read are in pieces j and j + 8, which would otherwise share their banks.
+template <int TM, bool M16>
 __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
+  static_assert(!M16 || TM == 4, "M16: 16 pieces of two pixel rows per operand stage");
   constexpr int WM = 2, WN = 4, TN = 2, NW = 8, NSTG = 3;
   constexpr int BNT = WM * TM * 32;          // output channels per tile
   constexpr int AROW = BNT * 2;              // bytes of a dY pixel row in the tile
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
   constexpr int AIW = NI_A / NW;             // dY pieces per wave per step (2 or 1)
   constexpr int XIW = NI_X / NW;             // X pieces per wave per step (2)
   constexpr int NLOAD = AIW + XIW;
-  constexpr int A_BYTES = NI_A * PIECE, X_BYTES = NI_X * PIECE;
+  constexpr int SKEW = M16 ? 32 : 0;
+  constexpr int A_BYTES = NI_A * PIECE + SKEW, X_BYTES = NI_X * PIECE + SKEW;
   constexpr int STAGE = A_BYTES + X_BYTES;
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -112,13 +117,21 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
     x_const[i] = lane_xoff;
   }
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  f32x4 acc4[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];  // M16: [16-channel block of dY][16-column block of the gradient]
+  if constexpr (M16) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < 2 * TN; ++b) acc4[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
 
   int istep = 0;  // next step to request
   auto issue_step = [&](int stage) {
@@ -126,13 +139,13 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
     char* Xs = As + A_BYTES;
     const unsigned soff = (unsigned)(istep * PS * g.ldo * 2);
 #pragma unroll
-    for (int i = 0; i < AIW; ++i) buffer_to_lds16(p.dy, p.dy_bytes, As + (wid * AIW + i) * PIECE, a_off[i], soff);
+    for (int i = 0; i < AIW; ++i) buffer_to_lds16(p.dy, p.dy_bytes, As + (wid * AIW + i) * PIECE + ((wid * AIW + i) >= 8 ? SKEW : 0), a_off[i], soff);
 #pragma unroll
     for (int i = 0; i < XIW; ++i) {
       const int iy = x_my[i] * g.iys + tdy, ix = x_mx[i] * g.ixs + tdx;
       const bool ok = slab_ok && x_img[i] < g.B && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
       const unsigned voff = (unsigned)(((x_img[i] * g.IH + iy - tdy) * g.IW + ix - tdx) * g.ldi * 2) + x_const[i];
-      buffer_to_lds16(p.x, p.x_bytes, Xs + (wid * XIW + i) * PIECE, ok ? voff : OOB, 0);
+      buffer_to_lds16(p.x, p.x_bytes, Xs + (wid * XIW + i) * PIECE + ((wid * XIW + i) >= 8 ? SKEW : 0), ok ? voff : OOB, 0);
       // next step: 32 pixels on (an output row holds at least 32: one wrap at most)
       x_mx[i] += PS;
       if (x_mx[i] >= g.MW) {
@@ -146,58 +159,115 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
 #pragma unroll
   for (int st = 0; st < NSTG - 1; ++st) issue_step(st);
 
-  // fragment addressing (see conv_wgrad_k): a 16-lane group reads pixel rows prow + q, q = 0..3 (lo) and + 4 (hi), 8 bytes
-  // (4 channels) per lane; after the transpose a lane holds 8 consecutive pixels of channel / k-column (lane & 31)
-  const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-  int fa[2][2], fb[2][2];  // [sub-step][lo / hi]
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  if constexpr (M16) {
+    // lane -> (pixel octet gq, pixel q (+4 for the second read), channels 4*pp..+3 of a 16-channel block); pixel 8*gq + q + 4*h is
+    // row gq >> 1 of piece 8*(gq & 1) + q + 4*h
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    int fa[2], fb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int prow = ks * 16 + 8 * (gq >> 1) + q + 4 * h;
-      fa[ks][h] = (prow % NI_A) * PIECE + (prow / NI_A) * AROW + ((wm * TM * 32) + (gq & 1) * 16 + 4 * pp) * 2;
-      fb[ks][h] = A_BYTES + (prow % NI_X) * PIECE + (prow / NI_X) * XROW + ((wn * TN * 32) + (gq & 1) * 16 + 4 * pp) * 2;
+      const int piece = 8 * (gq & 1) + q + 4 * h, row = gq >> 1;
+      const int base = piece * PIECE + ((gq & 1) ? SKEW : 0);
+      fa[h] = base + row * AROW + (wm * TM * 32 + 4 * pp) * 2;
+      fb[h] = A_BYTES + base + row * XROW + (wn * TN * 32 + 4 * pp) * 2;
     }
-
-  half8_t a0[TM], b0[TN], a1[TM], b1[TN];
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int t = 0; t < TM; ++t) a0[t] = read_tr(smem + fa[0][0] + t * 64, smem + fa[0][1] + t * 64);
-#pragma unroll
-  for (int t = 0; t < TN; ++t) b0[t] = read_tr(smem + fb[0][0] + t * 64, smem + fb[0][1] + t * 64);
-
-  int stage = 0;
-  for (int st = 0; st < nsteps; ++st) {
-    const char* S = smem + stage * STAGE;
-    const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
-#pragma unroll
-    for (int t = 0; t < TM; ++t) a1[t] = read_tr(S + fa[1][0] + t * 64, S + fa[1][1] + t * 64);
-#pragma unroll
-    for (int t = 0; t < TN; ++t) b1[t] = read_tr(S + fb[1][0] + t * 64, S + fb[1][1] + t * 64);
-    issue_step(stage == 0 ? NSTG - 1 : stage - 1);  // steps past the chunk: rows the MFMAs below never read again
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOAD) : "memory");
+    // per step: dY blocks 0..3 (aL) x the 4 column blocks, then blocks 4..7 (aH); the fragments of the second half are requested
+    // before the MFMAs of the first, those of the next step (aL and the OTHER set of column fragments) before the MFMAs of the second
+    half8_t aL[TM], aH[TM], bA[2 * TN], bB[2 * TN];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* Sn = smem + nstage * STAGE;
 #pragma unroll
-    for (int t = 0; t < TM; ++t) a0[t] = read_tr(Sn + fa[0][0] + t * 64, Sn + fa[0][1] + t * 64);
+    for (int t = 0; t < TM; ++t) aL[t] = read_tr(smem + fa[0] + t * 32, smem + fa[1] + t * 32);
 #pragma unroll
-    for (int t = 0; t < TN; ++t) b0[t] = read_tr(Sn + fb[0][0] + t * 64, Sn + fb[0][1] + t * 64);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < 2 * TN; ++t) bA[t] = read_tr(smem + fb[0] + t * 32, smem + fb[1] + t * 32);
+    int stage = 0;
+    auto step = [&](half8_t (&bc)[2 * TN], half8_t (&bn)[2 * TN]) {
+      const char* S = smem + stage * STAGE;
+      const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int t = 0; t < TM; ++t) aH[t] = read_tr(S + fa[0] + (TM + t) * 32, S + fa[1] + (TM + t) * 32);
+      issue_step(stage == 0 ? NSTG - 1 : stage - 1);  // steps past the chunk: rows the MFMAs below never read again
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[tm], b1[tn], acc[tm][tn], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    stage = nstage;
+      for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2 * TN; ++tb) acc4[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aL[ta], bc[tb], acc4[ta][tb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOAD) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* Sn = smem + nstage * STAGE;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) aL[t] = read_tr(Sn + fa[0] + t * 32, Sn + fa[1] + t * 32);
+#pragma unroll
+      for (int t = 0; t < 2 * TN; ++t) bn[t] = read_tr(Sn + fb[0] + t * 32, Sn + fb[1] + t * 32);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2 * TN; ++tb) acc4[TM + ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH[ta], bc[tb], acc4[TM + ta][tb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      stage = nstage;
+    };
+    for (int st = 0; st < nsteps; st += 2) {
+      step(bA, bB);
+      if (st + 1 < nsteps) step(bB, bA);
+    }
+  } else {
+  // fragment addressing (see conv_wgrad_k): a 16-lane group reads pixel rows prow + q, q = 0..3 (lo) and + 4 (hi), 8 bytes
+    // (4 channels) per lane; after the transpose a lane holds 8 consecutive pixels of channel / k-column (lane & 31)
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    int fa[2][2], fb[2][2];  // [sub-step][lo / hi]
+  #pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+  #pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int prow = ks * 16 + 8 * (gq >> 1) + q + 4 * h;
+        fa[ks][h] = (prow % NI_A) * PIECE + (prow / NI_A) * AROW + ((wm * TM * 32) + (gq & 1) * 16 + 4 * pp) * 2;
+        fb[ks][h] = A_BYTES + (prow % NI_X) * PIECE + (prow / NI_X) * XROW + ((wn * TN * 32) + (gq & 1) * 16 + 4 * pp) * 2;
+      }
+  
+    half8_t a0[TM], b0[TN], a1[TM], b1[TN];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  #pragma unroll
+    for (int t = 0; t < TM; ++t) a0[t] = read_tr(smem + fa[0][0] + t * 64, smem + fa[0][1] + t * 64);
+  #pragma unroll
+    for (int t = 0; t < TN; ++t) b0[t] = read_tr(smem + fb[0][0] + t * 64, smem + fb[0][1] + t * 64);
+  
+    int stage = 0;
+    for (int st = 0; st < nsteps; ++st) {
+      const char* S = smem + stage * STAGE;
+      const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
+  #pragma unroll
+      for (int t = 0; t < TM; ++t) a1[t] = read_tr(S + fa[1][0] + t * 64, S + fa[1][1] + t * 64);
+  #pragma unroll
+      for (int t = 0; t < TN; ++t) b1[t] = read_tr(S + fb[1][0] + t * 64, S + fb[1][1] + t * 64);
+      issue_step(stage == 0 ? NSTG - 1 : stage - 1);  // steps past the chunk: rows the MFMAs below never read again
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOAD) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* Sn = smem + nstage * STAGE;
+  #pragma unroll
+      for (int t = 0; t < TM; ++t) a0[t] = read_tr(Sn + fa[0][0] + t * 64, Sn + fa[0][1] + t * 64);
+  #pragma unroll
+      for (int t = 0; t < TN; ++t) b0[t] = read_tr(Sn + fb[0][0] + t * 64, Sn + fb[0][1] + t * 64);
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[tm], b1[tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      stage = nstage;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -205,28 +275,46 @@ __global__ __launch_bounds__(512) void wgrad_ring_k(const WrParams p) {
   // stores of the unscaled partial tile into this pixel chunk's slab (am_conv_wgrad_ws sums the slabs in a second pass: no
   // device-scope atomics, which run at ~1.3 TB/s of added bytes chip-wide and cost this kernel ~30 %); else fp32 atomics ----
   float* part = p.ws ? p.ws + (size_t)mcid * p.ws_stride : nullptr;
+  if constexpr (M16) {
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int kc = kt * 256 + (wn * TN + tn) * 32 + (lane & 31);
-    if (kc >= p.Ktot) continue;
+    for (int tb = 0; tb < 2 * TN; ++tb) {
+      const int kc = kt * 256 + wn * TN * 32 + tb * 16 + (lane & 15);
+      if (kc >= p.Ktot) continue;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int ta = 0; ta < 2 * TM; ++ta)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N) {
-          if (part) part[(size_t)n * p.Ktot + kc] = acc[tm][tn][r];
-          else atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wm * TM * 32 + ta * 16 + 4 * (lane >> 4) + j;
+          if (n < g.N) {
+            if (part) part[(size_t)n * p.Ktot + kc] = acc4[ta][tb][j];
+            else atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc4[ta][tb][j] * p.scale);
+          }
         }
-      }
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int kc = kt * 256 + (wn * TN + tn) * 32 + (lane & 31);
+      if (kc >= p.Ktot) continue;
+  #pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (n < g.N) {
+            if (part) part[(size_t)n * p.Ktot + kc] = acc[tm][tn][r];
+            else atomicAdd(p.dw + (size_t)n * p.Ktot + kc, acc[tm][tn][r] * p.scale);
+          }
+        }
+    }
   }
 }
 
-template <int TM>
+template <int TM, bool M16>
 int launch(const WrParams& p0, hipStream_t s, bool plan_only) {
   constexpr int BNT = 2 * TM * 32;
   constexpr int NI_A = PS / (1024 / (BNT * 2));
-  constexpr int LDS = 3 * (NI_A + NI_X) * PIECE;
+  constexpr int LDS = 3 * ((NI_A + NI_X) * PIECE + (M16 ? 64 : 0));
   WrParams p = p0;
   p.ntiles = am_cdiv(p.g.N, BNT);
   p.ktiles = am_cdiv(p.nslab, 8);
@@ -245,12 +333,12 @@ int launch(const WrParams& p0, hipStream_t s, bool plan_only) {
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_k<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_k<TM, M16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   g_am_conv_variant = AM_CV_WGRAD_RING;
-  hipLaunchKernelGGL((wgrad_ring_k<TM>), dim3(tiles * p.mchunks), dim3(512), LDS, s, p);
+  hipLaunchKernelGGL((wgrad_ring_k<TM, M16>), dim3(tiles * p.mchunks), dim3(512), LDS, s, p);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -284,6 +372,7 @@ int am_conv_wgrad_ring_f16(const am_conv_geom* g, const void* x, const void* dy,
   p.ktiles = p.ntiles = p.mchunks = p.mc = 0;
   for (int t = 0; t < AM_MAX_TAPS; ++t)
     p.tap_off[t] = t < g->ntaps ? (int)(((long long)g->dy[t] * g->IW + g->dx[t]) * (long long)g->ldi * 2) : 0;
-  if (g->N % 256 == 0) return launch<4>(p, s, plan_only);
-  return launch<2>(p, s, plan_only);
+  // (16x16x32 on the 256-channel tile: 1-2 % less time per launch in isolation, 0.4 % MORE per cfg2 step -- not the default)
+  if (g->N % 256 == 0) return am_tuning(AM_TUNE_WGRAD_RING) == 2 ? launch<4, true>(p, s, plan_only) : launch<4, false>(p, s, plan_only);
+  return launch<2, false>(p, s, plan_only);
 }

@@ -889,7 +889,7 @@ def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
     assert B * geom.OH * geom.OW >= 16384 and geom.OW >= 32
     outs = []
     L = hc._L()
-    for ring in (1, 0):
+    for ring in (1, 0, 2):  # 1: the ring kernel, 2: its 16x16x32 MFMA form on the 256-channel tile
         dwp = torch.zeros(cout, geom.ntaps * geom.krun, dtype=torch.float32, device=_dev())
         old = L.am_set_tuning(2, ring)  # AM_TUNE_WGRAD_RING: 0 pins the register-staged kernel on the same geometry
         try:
@@ -900,6 +900,7 @@ def test_wgrad_ring_kernel_vs_torch_and_register_staged_kernel(case):
         outs.append(hc.unpack_wgrad(dwp, spec, torch.float16).cpu())
     assert rel_err(outs[0], w.grad) < 2e-3
     assert rel_err(outs[0], outs[1]) < 1e-3
+    assert rel_err(outs[0], outs[2]) < 1e-5  # the two MFMA forms: same products, fp32 sums in another order
 
 
 @pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 96, 100, True), (128, 256, 3, 2, 1, 2, 370, 361, False), (64, 256, 3, 1, 1, 4, 128, 128, False)])
