@@ -422,6 +422,9 @@ class AutoMoE(nn.Module):
                 "speed_seq": spd, "expert_weights": g["expert_weights"], "expert_outputs": outs,
                 "context_features": ctx, "combined_features": g["combined_output"], "gate_logits": g["gate_logits"]}
 
+    def get_expert_weights(self, batch):  # automoe.py:235-238: gate weights from the context alone (zero expert features)
+        return self.gating_network.get_expert_weights(self._context(batch))
+
     def freeze_experts(self):
         for p in self.experts.parameters():
             p.requires_grad = False
