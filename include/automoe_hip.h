@@ -93,7 +93,14 @@ int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, const void* w,
  * (conv -> BatchNorm2d(batch statistics) -> ReLU of bdd_*_expert.py:9-11 without writing the raw conv output):
  *   mode 1: accumulate the BatchNorm statistics of the conv output into `stats`, write nothing;
  *   mode 2: y = relu(conv * scale[n] + shift[n]) with scale/shift from am_bn_finalize;
- *   mode 3: y = MaxPool2d(3,2,1)(relu(conv * scale[n] + shift[n])), y = [B,(OH-1)/2+1,(OW-1)/2+1,ldo] (ResNet stem + maxpool).
+ *   mode 3: y = MaxPool2d(3,2,1)(relu(conv * scale[n] + shift[n])), y = [B,(OH-1)/2+1,(OW-1)/2+1,ldo] (ResNet stem + maxpool);
+ *   mode 4: the whole frozen stem in ONE pass over the image: `scale` = the BatchNorm weight gamma[64] (only its signs are
+ *           used), y = MaxPool2d(3,2,1)(s[n] * conv) with s[n] = -1 where gamma[n] < 0 else +1 (the f16-rounded conv output
+ *           pooled as it is), and `stats` += the BatchNorm sums of s * conv.  MaxPool commutes with the per-channel monotone
+ *           map v -> relu(v * scale + shift) (torchvision resnet.py: conv1 -> bn1 -> relu -> maxpool, bdd_*_expert.py:9-11), so
+ *           the consumers apply it to the POOLED map: am_bn_finalize_signed turns the sums into scale >= 0 / shift for s * conv,
+ *           am_conv_gemm_prebn / am_bn_apply2 (relu bit 1) / am_bn_apply consume (y, scale, shift).  Equal bit for bit to
+ *           am_conv_gemm -> am_bn_apply(relu) -> am_maxpool3x3s2_fwd given the same statistics.
  * Returns AM_ERR_UNSUPPORTED when the geometry / size is not covered (caller uses am_conv_gemm + am_bn_apply). */
 int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, const void* x, const void* w, const float* scale,
                         const float* shift, void* y, double* stats, am_stream_t stream);
@@ -217,11 +224,19 @@ int am_bn_finalize(const double* stats, int nrep, double count, const float* con
                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                    int training, float* scale, float* shift, float* save_mean, float* save_rstd, int C,
                    am_stream_t stream);
+/* am_bn_finalize (training) for sums taken on x' = s * x, s[c] = -1 where gamma[c] < 0 else +1 (am_conv_first_fused mode 4):
+ * scale = |gamma| * rstd, shift = beta - mean(x') * scale -- the affine map for x' --, running_mean / running_var updated
+ * with the statistics of x itself (mean(x) = s * mean(x'), var(x) = var(x')). */
+int am_bn_finalize_signed(const double* stats, int nrep, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                          int C, am_stream_t stream);
 int am_bn_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                 int relu, void* y, int ldy, long long P, int C, am_stream_t stream);
 /* am_bn_apply whose residual is itself a raw conv output normalised on the fly (the downsample branch of a strided
  * BasicBlock: y = relu(bn2(conv2) + bn_d(conv_d)), torchvision resnet.py BasicBlock.forward): res' = round(res*res_scale +
- * res_shift) as a separate am_bn_apply pass would have stored it.  res_scale/res_shift both NULL: am_bn_apply. */
+ * res_shift) as a separate am_bn_apply pass would have stored it.  res_scale/res_shift both NULL: am_bn_apply.
+ * relu: bit 0 = ReLU on the sum (as am_bn_apply), bit 1 = ReLU on the transformed residual before it is rounded (the residual
+ * is a BatchNorm + ReLU output that was never written: the pooled stem of am_conv_first_fused mode 4 feeding layer1's block). */
 int am_bn_apply2(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr,
                  const float* res_scale, const float* res_shift, int relu, void* y, int ldy, long long P, int C,
                  am_stream_t stream);

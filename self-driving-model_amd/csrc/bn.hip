@@ -10,10 +10,14 @@ namespace {
 __global__ void bn_finalize_k(const double* __restrict__ stats, int nrep, double count, const float* __restrict__ conv_bias,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                               float* running_var, float momentum, float eps, int training, float* scale, float* shift,
-                              float* save_mean, float* save_rstd, int C) {
+                              float* save_mean, float* save_rstd, int C, int sgn_stats) {
+  // sgn_stats (am_bn_finalize_signed): the sums were taken on x' = sgn(gamma) * x (am_conv_first_fused mode 4).  mean(x) =
+  // sgn * mean(x'), var(x) = var(x'); the emitted scale / shift apply to x':  gamma * (x - mean) * rstd + beta =
+  // |gamma| * (x' - mean') * rstd + beta, so scale = |gamma| * rstd >= 0 and shift = beta - mean' * scale.
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, rstd;
+  const float gsign = (sgn_stats && gamma && gamma[c] < 0.f) ? -1.f : 1.f;
   if (training) {
     // all replica loads in flight at once: issued one per iteration (runtime trip count, dependent adds) the 2*nrep L2 round
     // trips were most of this tiny kernel's 8 us
@@ -34,17 +38,17 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, int nrep, double
     rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (gsign * mean);
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   } else {
     mean = running_mean[c];
     rstd = 1.0f / sqrtf(running_var[c] + eps);
   }
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = (gamma ? gamma[c] : 1.f) * gsign, b = beta ? beta[c] : 0.f;
   scale[c] = g * rstd;
   shift[c] = b - mean * g * rstd;
-  if (save_mean) save_mean[c] = mean;
+  if (save_mean) save_mean[c] = gsign * mean;
   if (save_rstd) save_rstd[c] = rstd;
 }
 
@@ -102,9 +106,13 @@ __global__ __launch_bounds__(256) void bn_apply_k(const T* __restrict__ x, int l
         // a raw residual (the downsample conv's output) is normalised here, rounded to T first like the tensor a separate
         // am_bn_apply pass would have written
         const float r = am_to_f32(rv.v[e]);
-        v += RAFF ? am_to_f32(am_from_f32<T>(r * rs[e] + rh[e])) : r;
+        // (relu & 2: the residual is itself a BatchNorm + ReLU output that was never written -- the ResNet stem behind the
+        // one-pass pool, am_conv_first_fused mode 4)
+        float ra = r * rs[e] + rh[e];
+        if (RAFF && (relu & 2)) ra = fmaxf(ra, 0.f);
+        v += RAFF ? am_to_f32(am_from_f32<T>(ra)) : r;
       }
-      if (relu) v = fmaxf(v, 0.f);
+      if (relu & 1) v = fmaxf(v, 0.f);
       out.v[e] = am_from_f32<T>(v);
     }
     *reinterpret_cast<Vec16<T>*>(y + pix * ldy + c0) = out;
@@ -124,15 +132,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* __restrict__ dy,
   // output x * scale + shift (am_bn_apply's fp32 arithmetic) -- recomputed from the conv output that is read anyway instead of
   // reading the activation tensor
   constexpr int E = 16 / (int)sizeof(T);
-  extern __shared__ float red[];  // [256][2*E]
+  using S = typename am_stat_acc<T>::type;  // double in fp32 parity mode (torch-CPU's accumulation type), float for f16
+  extern __shared__ char red_raw[];
+  S* red = reinterpret_cast<S*>(red_raw);  // [256][2*E]
   const int cpr = C / E;
   const int tid = threadIdx.x;
   // threads are laid out [rows_per_pass][cpr]; threads beyond rows_per_pass*cpr idle
   const int rpp = 256 / cpr > 0 ? 256 / cpr : 1;
   const int chunk = tid % cpr, rloc = tid / cpr;
-  float s[E], q[E];
+  S s[E], q[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) s[e] = q[e] = 0.f;
+  for (int e = 0; e < E; ++e) s[e] = q[e] = (S)0;
   if (cpr <= 256 && rloc < rpp) {
     const int c0 = chunk * E;
     float mu[E], rs[E], sc[E], sh[E];
@@ -150,8 +160,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* __restrict__ dy,
         const float xf = am_to_f32(xv.v[e]);
         if (mask_y && !(am_to_f32(yo.v[e]) > 0.f)) dz = 0.f;
         if (sign && !(xf * sc[e] + sh[e] > 0.f)) dz = 0.f;
-        s[e] += dz;
-        q[e] += dz * (xf - mu[e]) * rs[e];
+        s[e] += (S)dz;
+        if constexpr (sizeof(S) == 8) q[e] += (double)dz * ((double)xf - (double)mu[e]) * (double)rs[e];
+        else q[e] += dz * (xf - mu[e]) * rs[e];
       }
     };
     // two rows per iteration, all their loads issued first: with one row (2-3 loads of 16 B per thread, four waves per SIMD) the
@@ -354,7 +365,18 @@ extern "C" int am_bn_finalize(const double* stats, int nrep, double count, const
   if (!training && (!running_mean || !running_var)) return AM_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), stats, nrep, count,
                      conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
-                     save_rstd, C);
+                     save_rstd, C, 0);
+  AM_CHECK_LAUNCH();
+  return AM_OK;
+}
+
+extern "C" int am_bn_finalize_signed(const double* stats, int nrep, double count, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                     float* shift, int C, am_stream_t stream) {
+  if (C <= 0 || !scale || !shift || !gamma || !stats || count <= 0.0 || nrep > AM_STATS_REPLICAS) return AM_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_k, dim3(am_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), stats, nrep, count,
+                     (const float*)nullptr, gamma, beta, running_mean, running_var, momentum, eps, 1, scale, shift,
+                     (float*)nullptr, (float*)nullptr, C, 1);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -407,7 +429,7 @@ static int bn_bwd_reduce_impl(int dtype, const void* dy, int lddy, const void* y
   int grid = (int)((P + rpp * 8 - 1) / (rpp * 8));
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
-  const size_t lds = 256 * 2 * E * sizeof(float);
+  const size_t lds = 256 * 2 * E * (dtype == AM_F16 ? sizeof(float) : sizeof(double));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == AM_F16)
     hipLaunchKernelGGL(bn_bwd_reduce_k<half_t>, dim3(grid), dim3(256), lds, s, (const half_t*)dy, lddy, (const half_t*)yout, ldyo, (const half_t*)x, ldx, mean, rstd, relu, sums, P, C, sg_scale, sg_shift);

@@ -138,6 +138,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  double dacc[sizeof(T) == 4 ? TM : 1][sizeof(T) == 4 ? TN : 1][16];  // fp32 parity mode: master accumulator (see the K-loop)
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[a][b][r] = 0.0;
+  }
+
   uint4 ra0, ra1, ra2, ra3, rb0, rb1;  // scalars, not an array: hipcc keeps an indexed array captured by the lambdas in scratch
   static_assert(AR <= 4, "A loader handles at most 4 rows per thread");
   static_assert(BCH <= 2, "B tile loader handles at most 128 rows");
@@ -207,6 +217,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
           for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     } else {
+      // fp32 parity mode: the 16 products of a K-step are summed by the exact-fp32 MFMA chain into a FRESH partial, the partials
+      // into a double master accumulator.  One fp32 chain over the whole contraction (2,304 dependent MFMA steps for a
+      // 512-channel 3x3 layer) left every block output ~1.6x farther from an fp64 run than torch-CPU's vectorised FMA sums
+      // (scratch/dbg_bn_b16.py, round 3) -- and with train-mode BatchNorm + ReLU that noise decides which near-zero
+      // activations flip, i.e. whether a gradient lands 1e-6 or 5e-3 from the fp64 result.
+      f32x16 part[TM][TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[tm][tn][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         float a[TM], b[TN];
@@ -217,24 +239,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn) part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], part[tm][tn], 0, 0, 0);
       }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dacc[tm][tn][r] += (double)part[tm][tn][r];
     }
     if (kk + 1 < p.nk) store_tile(stage ^ 1);
     __syncthreads();
   }
 
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = (float)dacc[a][b][r];  // ONE rounding of the whole contraction
+  }
+
   // ---- epilogue: BN statistics (pre-bias accumulator), bias, ReLU, store ----
   if (p.stats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; stage buffers are free after the last barrier
+    // (per-lane partials in double in fp32 parity mode, am_common.h am_stat_acc: torch-CPU's accumulation type)
+    using S = typename am_stat_acc<T>::type;
+    S* red = reinterpret_cast<S*>(smem);  // [WM][BN][2]; stage buffers are free after the last barrier
+    static_assert(WM * BN * 2 * (int)sizeof(S) <= 2 * STAGE, "statistics scratch must fit the stage buffers");
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      float s = 0.f, q = 0.f;
+      S s = (S)0, q = (S)0;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = acc[tm][tn][r];
+          const S v = (S)acc[tm][tn][r];
           s += v;
           q += v * v;
         }
@@ -435,6 +475,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  double dacc[sizeof(T) == 4 ? TMN : 1][sizeof(T) == 4 ? TNK : 1][16];  // fp32 parity mode: master accumulator
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int a = 0; a < TMN; ++a)
+#pragma unroll
+      for (int b = 0; b < TNK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[a][b][r] = 0.0;
+  }
+
   // PS*4 loader threads per step: thread -> pixel row (tid>>2), 16-byte lane (tid&3)
   const bool loader = (tid >> 2) < PS;
   uint4 rdy[DCH], rx[NS];
@@ -499,6 +549,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
           for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     } else {
+      // fp32 parity mode: a fresh fp32 partial per 32-pixel step, summed into a double master (conv_gemm_k's reasoning; the
+      // contraction here runs over every pixel of the chunk)
+      f32x16 part[TMN][TNK];
+#pragma unroll
+      for (int tm = 0; tm < TMN; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TNK; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[tm][tn][r] = 0.f;
 #pragma unroll 4
       for (int ks = 0; ks < PS / 2; ++ks) {
         float a[TMN], b[TNK];
@@ -510,11 +569,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 #pragma unroll
         for (int tm = 0; tm < TMN; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TNK; ++tn) part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], part[tm][tn], 0, 0, 0);
       }
+#pragma unroll
+      for (int tm = 0; tm < TMN; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TNK; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dacc[tm][tn][r] += (double)part[tm][tn][r];
     }
   }
 
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int a = 0; a < TMN; ++a)
+#pragma unroll
+      for (int b = 0; b < TNK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = (float)dacc[a][b][r];
+  }
   // flush, rows = output channel n, cols = packed k: plain stores into this pixel chunk's slab (slab mode) or fp32 atomics
   float* slab = p.ws ? p.ws + (size_t)mcid * p.ws_stride : nullptr;
 #pragma unroll
@@ -857,6 +930,7 @@ extern "C" int am_conv_first_fused(const am_conv_geom* g, int dtype, int mode, c
   int rc = check_geom(g, dtype);
   if (rc != AM_OK) return rc;
   if (dtype != AM_F16) return AM_ERR_UNSUPPORTED;
-  if (!x || !w || (mode == 1 && !stats) || ((mode == 2 || mode == 3) && (!y || !scale || !shift)) || mode < 1 || mode > 3) return AM_ERR_ARG;
+  if (!x || !w || (mode == 1 && !stats) || ((mode == 2 || mode == 3) && (!y || !scale || !shift)) || (mode == 4 && (!y || !scale || !stats)) || mode < 1 || mode > 4)
+    return AM_ERR_ARG;
   return am_conv_s2d_f16(g, mode, x, w, nullptr, scale, shift, 1, y, stats, static_cast<hipStream_t>(stream));
 }

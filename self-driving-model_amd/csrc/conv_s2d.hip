@@ -12,6 +12,9 @@
 //   1  BatchNorm statistics only, nothing written                  -- pass 1 of the fused stem
 //   2  y = relu(conv * scale[n] + shift[n])                        -- pass 2: BN(train) + ReLU applied in the epilogue
 //   3  y = maxpool3x3s2(relu(conv * scale[n] + shift[n]))          -- pass 2 of the ResNet stem: only the pooled map is written
+//   4  y = maxpool3x3s2(sgn(gamma[n]) * conv) + statistics of sgn * conv  -- the frozen train-mode stem in ONE pass (round 3):
+//      max-pool commutes with the monotone map v -> f16(relu(v * scale + shift)), so the normalisation moves behind the pool
+//      (into the consumers' input staging); a channel with gamma < 0 is pooled on the negated conv output (min instead of max).
 // Pass 1 + pass 2 recompute the (cheap) conv instead of writing the raw output, reading it back for the normalise
 // pass and writing it again: 0.47 GB instead of 3.3 GB of HBM traffic per 32 images for the ResNet stem.
 #include "am_common.h"
@@ -414,7 +417,12 @@ __device__ __forceinline__ void pool_mfma(const char* pt, const char* Wl, int wi
   }
 }
 
-template <int TAPS>
+// RAW (mode 4): no BatchNorm / ReLU in the epilogue -- the f16-rounded conv output is pooled as it is, with the weight rows of
+// channels whose gamma is negative NEGATED in LDS once per workgroup (conv' = sgn * conv bit for bit: every product and every
+// partial sum just changes sign), and the BatchNorm statistics of conv' are accumulated over the conv pixels this tile OWNS
+// (local rows 1..14, columns 1..30: row / column 0 belong to the previous tile, 15 / 31 are the spare ones) from the fp32
+// accumulators, as the statistics pass did.  Out-of-image conv positions count as -inf (raw values have both signs).
+template <int TAPS, bool RAW>
 __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int POH, int POW, int ptiles_y, int ptiles_x) {
   constexpr int NT = 2, NCH = 64;
   constexpr int PH = CTH + TAPS - 1, PW = CTW + TAPS - 1;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* zl = reinterpret_cast<const char*>(g_zero_line);
   const int ktot_bytes = TAPS * 64 * 2;
-  if (tid < 2 * NCH) bnc[tid] = tid < NCH ? p.scale[tid] : p.shift[tid - NCH];
+  if (!RAW && tid < 2 * NCH) bnc[tid] = tid < NCH ? p.scale[tid] : p.shift[tid - NCH];
 
   for (int inst = wid; inst < W_BYTES / 1024; inst += 8) {
     const int q = inst * 64 + lane;
@@ -472,8 +480,24 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
   if (tile < p.ntiles) issue_patch(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (RAW) {  // negate the resident weight rows of the channels with gamma < 0 (p.scale = gamma here)
+    constexpr int DW_ROW = KSTEPS * 8;  // dwords of weights per row (the 16-byte pad is left alone)
+    for (int i = tid; i < NCH * DW_ROW; i += 512) {
+      const int n = i / DW_ROW, d = i - n * DW_ROW;
+      if (p.scale[n] < 0.f) {
+        unsigned* wp = reinterpret_cast<unsigned*>(Wl + n * WPITCH) + d;
+        *wp ^= 0x80008000u;
+      }
+    }
+    __syncthreads();
+  }
 
   const int rx = lane & 31, kg = lane >> 5;
+  f32x4 ssum[NT][4], ssq[NT][4];  // RAW: this lane's statistics partials (2 x 16 channels of its pixel column), all tiles
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ssum[tn][q] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[tn][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   // Second half of a tile's epilogue (needs the row exchanged at the barrier): vertical window with the next wave's
   // first row, horizontal window by DPP, pooled row out through the wave's staging strip.
   auto pool_out = [&](int t, int tbuf, const half4_t (&v)[NT][4]) {
@@ -522,7 +546,7 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
   // left alone the partners would reach their MFMA phases and their (VALU-only) epilogues together.  The previous tile's
   // pool_out is therefore placed differently: waves 0..3 run it right after the barrier, before their MFMAs; waves 4..7
   // start their MFMAs at once and run it between the two halves of the tap loop.
-  const bool late = wid >= 4;
+  const bool late = !RAW && wid >= 4;  // (RAW: the 64 statistics registers leave no room for pool_out's temporaries inside the MFMA phase: 6 spills)
   int buf = 0, ptile = -1;
   half4_t v[NT][4];
   for (; tile < p.ntiles; tile += gridDim.x) {
@@ -541,7 +565,29 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
     // BN + ReLU on packed registers; h0 = the wave's first row, v = max of its two rows.  Per (tn, q): channels
     // tn*32 + 8q + 4kg + (0..3) of column rx.
     half4_t h0[NT][4];
-    const half4_t z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    const half_t zv = RAW ? (half_t)(-__builtin_inff()) : (half_t)0.f;
+    const half4_t z = {zv, zv, zv, zv};
+    if constexpr (RAW) {
+      // statistics of the owned, in-image conv pixels (multiplier 0 / 1 per lane and row), then the plain f16 conversion
+      const bool colown = rx >= 1 && rx <= CTW - 2 && (unsigned)(cx0 + rx) < (unsigned)p.OW;
+      const float m0 = (colown && wid > 0 && (unsigned)(cy0 + 2 * wid) < (unsigned)p.OH) ? 1.f : 0.f;
+      const float m1 = (colown && wid < 7 && (unsigned)(cy0 + 2 * wid + 1) < (unsigned)p.OH) ? 1.f : 0.f;
+      const f32x4 m04 = {m0, m0, m0, m0}, m14 = {m1, m1, m1, m1};
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 a0 = {acc[0][tn][4 * q], acc[0][tn][4 * q + 1], acc[0][tn][4 * q + 2], acc[0][tn][4 * q + 3]};
+          const f32x4 a1 = {acc[1][tn][4 * q], acc[1][tn][4 * q + 1], acc[1][tn][4 * q + 2], acc[1][tn][4 * q + 3]};
+          const f32x4 b0 = a0 * m04, b1 = a1 * m14;
+          ssum[tn][q] += b0;
+          ssum[tn][q] += b1;
+          ssq[tn][q] = __builtin_elementwise_fma(b0, a0, ssq[tn][q]);
+          ssq[tn][q] = __builtin_elementwise_fma(b1, a1, ssq[tn][q]);
+          h0[tn][q] = __builtin_convertvector(a0, half4_t);
+          v[tn][q] = __builtin_convertvector(a1, half4_t);
+        }
+    } else {
     f32x4 scv[NT][4], shv[NT][4];  // BN constants of this lane's 2 x 16 channels: all reads issued before the first use
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
@@ -561,7 +607,8 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
         h0[tn][q] = __builtin_elementwise_max(__builtin_convertvector(__builtin_elementwise_fma(a0, sc4, sh4), half4_t), z);
         v[tn][q] = __builtin_elementwise_max(__builtin_convertvector(__builtin_elementwise_fma(a1, sc4, sh4), half4_t), z);
       }
-    // conv positions outside the image count as 0: only tiles on the image border have any (wave-uniform test)
+    }
+    // conv positions outside the image count as 0 (RAW: -inf): only tiles on the image border have any (wave-uniform test)
     if (cy0 < 0 || cx0 < 0 || cy0 + CTH > p.OH || cx0 + CTW > p.OW) {
       const bool colok = (unsigned)(cx0 + rx) < (unsigned)p.OW;
       const bool ok0 = colok && (unsigned)(cy0 + 2 * wid) < (unsigned)p.OH;
@@ -591,9 +638,51 @@ __global__ __launch_bounds__(512) void conv_s2d_pool_k(const S2dParams p, int PO
     buf ^= 1;
   }
   if (ptile >= 0) pool_out(ptile, buf ^ 1, v);
+  if constexpr (RAW) {
+    // fold the per-lane partials: over the 32 pixel columns of a half-wave (same kg = same channels), then over the eight
+    // waves through LDS, then one fp64 atomic pair per channel and workgroup (bn.hip's replica layout)
+    if (p.stats != nullptr) {
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = ssum[tn][q][e], b = ssq[tn][q][e];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            ssum[tn][q][e] = a; ssq[tn][q][e] = b;
+          }
+      __syncthreads();  // every wave is past its last use of xbuf
+      float* part = reinterpret_cast<float*>(xbuf);  // [8 waves][64 channels][2]
+      if (rx == 0) {
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ch = tn * 32 + 8 * q + 4 * kg + e;
+              part[(wid * NCH + ch) * 2 + 0] = ssum[tn][q][e];
+              part[(wid * NCH + ch) * 2 + 1] = ssq[tn][q][e];
+            }
+      }
+      __syncthreads();
+      if (tid < NCH) {
+        double sd = 0.0, qd = 0.0;
+        for (int a = 0; a < 8; ++a) {
+          sd += (double)part[(a * NCH + tid) * 2 + 0];
+          qd += (double)part[(a * NCH + tid) * 2 + 1];
+        }
+        double* st = p.stats + (size_t)(blockIdx.x % AM_STATS_REPLICAS) * 2 * NCH;
+        atomicAdd(st + tid, sd);
+        atomicAdd(st + NCH + tid, qd);
+      }
+    }
+  }
 }
 
-template <int TAPS>
+template <int TAPS, bool RAW>
 int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
   constexpr int PH = CTH + TAPS - 1, PW = CTW + TAPS - 1;
   constexpr int PATCH_SLOT = ((PH * PW * CB + 1023) / 1024) * 1024;
@@ -607,13 +696,13 @@ int launch_s2d_pool(const S2dParams& p0, int POH, int POW, hipStream_t s) {
   static bool attr_done_dev[AM_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[am_current_device()];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_pool_k<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_pool_k<TAPS, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return AM_ERR_LAUNCH;
     attr_done = true;
   }
   const int grid = p.ntiles < 256 ? p.ntiles : 256;
   g_am_conv_variant = AM_CV_S2D_POOL;
-  hipLaunchKernelGGL((conv_s2d_pool_k<TAPS>), dim3(grid), dim3(512), LDS, s, p, POH, POW, pty, ptx);
+  hipLaunchKernelGGL((conv_s2d_pool_k<TAPS, RAW>), dim3(grid), dim3(512), LDS, s, p, POH, POW, pty, ptx);
   AM_CHECK_LAUNCH();
   return AM_OK;
 }
@@ -651,10 +740,11 @@ int am_conv_s2d_f16(const am_conv_geom* g, int mode, const void* x, const void* 
   p.tiles_y = am_cdiv(g->OH, TH);
   p.tiles_x = am_cdiv(g->OW, TW);
   p.ntiles = p.B * p.tiles_y * p.tiles_x;
-  if (mode == 3) {
+  if (mode == 3 || mode == 4) {
     // y is the max-pooled map [B, POH, POW, ldo], POH = (OH-1)/2+1
     if (g->ntaps != 4 || g->N != 64) return AM_ERR_UNSUPPORTED;
-    return launch_s2d_pool<4>(p, (g->OH - 1) / 2 + 1, (g->OW - 1) / 2 + 1, s);
+    return mode == 3 ? launch_s2d_pool<4, false>(p, (g->OH - 1) / 2 + 1, (g->OW - 1) / 2 + 1, s)
+                     : launch_s2d_pool<4, true>(p, (g->OH - 1) / 2 + 1, (g->OW - 1) / 2 + 1, s);
   }
   if (mode == 0) return dispatch_s2d<0>(p, g->ntaps, s);
   if (mode == 1) return dispatch_s2d<1>(p, g->ntaps, s);

@@ -252,12 +252,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__
   const int cpr = C / E;
   const int BH = (IH + 1) / 2, BW = (IW + 1) / 2;
   const long long total = (long long)B * BH * BW * cpr;
-  float bs[E], bq[E], mu[E], rs[E], ssc[E], ssh[E];
+  using S = typename am_stat_acc<T>::type;  // double in fp32 parity mode (am_common.h)
+  S bs[E], bq[E];
+  float mu[E], rs[E], ssc[E], ssh[E];
   if (BNR) {
     const int c0 = (int)(threadIdx.x % cpr) * E;  // == (i % cpr) * E for every i of this thread (grid stride is a multiple of 256)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      bs[e] = bq[e] = 0.f;
+      bs[e] = bq[e] = (S)0;
       mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; ssc[e] = sg_scale[c0 + e]; ssh[e] = sg_shift[c0 + e];
     }
   }
@@ -327,8 +329,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__
             const float xf = am_to_f32(rv[e]);
             float dz = am_to_f32(o[e]);
             if (!(xf * ssc[e] + ssh[e] > 0.f)) dz = 0.f;
-            bs[e] += dz;
-            bq[e] += dz * (xf - mu[e]) * rs[e];
+            bs[e] += (S)dz;
+            if constexpr (sizeof(S) == 8) bq[e] += (double)dz * ((double)xf - (double)mu[e]) * (double)rs[e];
+            else bq[e] += dz * (xf - mu[e]) * rs[e];
           }
         }
       }
@@ -336,7 +339,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_block_k(const T* __restrict__
   }
   if (BNR) {
     // block reduction over the threads that share a channel chunk, then fp64 atomics into the replicas (as bn_bwd_reduce_k)
-    extern __shared__ float red[];  // [256][2E]
+    extern __shared__ char mp_red_raw[];
+    S* red = reinterpret_cast<S*>(mp_red_raw);  // [256][2E]
     const int tid = threadIdx.x, rpp = 256 / cpr;
 #pragma unroll
     for (int e = 0; e < E; ++e) { red[tid * 2 * E + e] = bs[e]; red[tid * 2 * E + E + e] = bq[e]; }
@@ -861,7 +865,7 @@ extern "C" int am_maxpool3x3s2_bwd_bn(int dtype, const void* dy, const uint8_t* 
   const long long total = (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * cpr;
   if (total == 0) return AM_OK;
   if (total >= (1ll << 31)) return AM_ERR_UNSUPPORTED;
-  const size_t lds = 256 * 2 * (16 / es) * sizeof(float);
+  const size_t lds = 256 * 2 * (16 / es) * (dtype == AM_F16 ? sizeof(float) : sizeof(double));
   if (dtype == AM_F16) hipLaunchKernelGGL((maxpool_bwd_block_k<half_t, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const half_t*)dy, argmax, (half_t*)dx, B, IH, IW, OH, OW, C, (const half_t*)raw, mean, rstd, scale, shift, sums);
   else hipLaunchKernelGGL((maxpool_bwd_block_k<float, true>), dim3(ew_grid(total)), dim3(256), lds, ST(stream), (const float*)dy, argmax, (float*)dx, B, IH, IW, OH, OW, C, (const float*)raw, mean, rstd, scale, shift, sums);
   AM_CHECK_LAUNCH();

@@ -330,6 +330,10 @@ class PackGroup:
         self.sig = None
         self.idx = self.buf = None
         self.active = []
+        # retired (idx, buf) pairs stay alive for the life of the group: a hipGraph captured before a re-layout has their
+        # addresses baked into its gather and conv nodes, and a replay must never write freed memory (re-layouts happen a handful
+        # of times per run -- first backward, a precision switch -- so the list stays short)
+        self._retired = []
 
     def refresh(self, dtype: torch.dtype):
         if not self.members:
@@ -346,6 +350,8 @@ class PackGroup:
                 parts.append(torch.where(pw.idx_dev >= 0, pw.idx_dev + off, pw.idx_dev))
                 total += pw.total
             assert self.flat_master.numel() < (1 << 31)
+            if self.buf is not None:
+                self._retired.append((self.idx, self.buf))
             self.idx = torch.cat(parts).to(torch.int32)
             self.buf = torch.empty(total, dtype=dtype, device=self.flat_master.device)
             self.sig, self.active = sig, active
@@ -457,7 +463,23 @@ def flush_bn_counters():
     if PENDING_BN_COUNTERS:
         torch._foreach_add_(list(PENDING_BN_COUNTERS), 1)
         PENDING_BN_COUNTERS.clear()
-    _RES_GRAD_STASH.clear()  # (end of a forward: nothing of an earlier, interrupted backward may leak into this step's)
+    if _RES_GRAD_STASH:
+        # a block-end backward parked the identity branch's gradient for conv1's backward and nothing took it: the shortcut
+        # gradient of that backward was DROPPED (an interrupted backward is the only legitimate way to get here)
+        import warnings
+        warnings.warn(f"{len(_RES_GRAD_STASH)} residual-gradient hand-off(s) of the previous backward were never consumed "
+                      f"(keys {list(_RES_GRAD_STASH)[:3]}): that backward lost its shortcut gradients")
+        _RES_GRAD_STASH.clear()
+
+
+def assert_residual_handoff_consumed():
+    """Called by FusedAdamW.step(): an update must never be made from a backward whose block-end gradients were parked for a
+    conv1 backward that did not pick them up (keys that no longer match, a conv1 routed through another path)."""
+    if _RES_GRAD_STASH:
+        keys = list(_RES_GRAD_STASH)[:3]
+        _RES_GRAD_STASH.clear()
+        raise RuntimeError(f"residual-gradient hand-off not consumed (keys {keys}): the shortcut gradient of a BasicBlock was dropped; "
+                           "set AUTOMOE_MERGE_RES_GRAD=0 to let autograd accumulate it and report this")
 
 
 class _Cfg:
@@ -778,12 +800,33 @@ def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
 
 
 @torch.no_grad()
-def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
+STEM_ONE_PASS = os.environ.get("AUTOMOE_STEM_ONE_PASS", "1") != "0"  # tests flip this to compare with the two-pass form
+
+
+class PendingAffine:
+    """A pooled stem map whose BatchNorm + ReLU is still to be applied: consumers read relu(raw * scale[c] + shift[c]) (scale >= 0;
+    am_conv_first_fused mode 4 / am_bn_finalize_signed).  `materialize()` writes that tensor for consumers without a fused form."""
+    __slots__ = ("raw", "scale", "shift")
+
+    def __init__(self, raw, scale, shift):
+        self.raw, self.scale, self.shift = raw, scale, shift
+
+    def materialize(self):
+        B, H, W, C = self.raw.shape
+        y = torch.empty_like(self.raw)
+        _L().am_bn_apply(dt_code(self.raw.dtype), ptr(self.raw), C, ptr(self.scale), ptr(self.shift), None, 0, 1, ptr(y), C, B * H * W, C, stream())
+        return y
+
+
+def fused_stem_pool(x, conv_w, bn, cfg: _Cfg, allow_pending: bool = False):
     """ResNet stem for a FROZEN trunk in train-mode BatchNorm: conv7x7/s2 -> BN(batch statistics, running stats
-    updated) -> ReLU -> MaxPool(3,2,1) as two passes over the space-to-depth image -- a statistics-only pass and a pass
-    whose epilogue normalises, rectifies and pools -- so neither the raw conv output nor the normalised map ever reaches
-    HBM.  Eval-mode BatchNorm (inference): the second pass alone, with scale / shift from the running statistics.
-    Returns the pooled NHWC activation, or None when the case is not covered (caller runs the unfused sequence)."""
+    updated) -> ReLU -> MaxPool(3,2,1) without the raw conv output or the normalised map ever reaching HBM.
+    Round 3 (allow_pending, STEM_ONE_PASS): ONE pass over the space-to-depth image -- the conv output is pooled raw (on
+    sign(gamma) * conv, so that a negative gamma pools the minimum) next to its BatchNorm sums, and the normalisation + ReLU,
+    which commute with the max-pool, are left to the consumers of the pooled map: the call returns a PendingAffine.
+    Otherwise two passes: a statistics-only pass and a pass whose epilogue normalises, rectifies and pools.
+    Eval-mode BatchNorm (inference): the second pass alone, with scale / shift from the running statistics.
+    Returns the pooled NHWC activation (or PendingAffine), or None when the case is not covered (caller runs the unfused sequence)."""
     import ctypes
     s = cfg.spec
     if not (FUSE_FIRST_LAYER and s.first and x.dtype == torch.float16 and bn is not None and s.cout == 64):
@@ -808,6 +851,31 @@ def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
     wp = cfg.cache.get_fwd(conv_w, s, x.dtype)
     scale = torch.empty(64, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
+    POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    if bn.training and STEM_ONE_PASS and allow_pending:
+        # ONE pass over the image (am_conv_first_fused mode 4): sign(gamma) * conv pooled raw + its BatchNorm sums; the
+        # normalisation + ReLU commute with the max-pool and are applied by the consumers of the pooled map (PendingAffine)
+        stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
+        y = torch.empty((B, POH, POW, 64), dtype=x.dtype, device=dev)
+        done = True
+        try:
+            _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * 64,
+                   lambda: L.am_conv_first_fused(ctypes.byref(g), AM_F16, 4, ptr(x), ptr(wp), ptr(bn.weight), None, ptr(y), ptr(stats), stream()))
+        except RuntimeError as e:
+            if "UNSUPPORTED" not in str(e):
+                raise
+            done = False
+        if done:
+            momentum = bn.momentum if bn.momentum is not None else 0.1
+            upd = bn.track_running_stats and bn.running_mean is not None
+            L.am_bn_finalize_signed(ptr(stats), AM_STATS_REPLICAS, float(P), ptr(bn.weight), ptr(bn.bias),
+                                    ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None, float(momentum),
+                                    float(bn.eps), ptr(scale), ptr(shift), 64, stream())
+            if upd:
+                _runtime().bump_stats_epoch()
+            if upd and bn.num_batches_tracked is not None:
+                PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+            return PendingAffine(y, scale, shift)
     if bn.training:
         stats = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * 64, dev)
         try:
@@ -830,7 +898,6 @@ def fused_stem_pool(x, conv_w, bn, cfg: _Cfg):
         # eval mode: scale / shift from the running statistics (am_bn_finalize's eval branch), ONE pass over the image
         L.am_bn_finalize(None, AM_STATS_REPLICAS, float(P), None, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
                          0.0, float(bn.eps), 0, ptr(scale), ptr(shift), None, None, 64, stream())
-    POH, POW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
     y = torch.empty((B, POH, POW, 64), dtype=x.dtype, device=dev)
     try:
         _timed("conv_gemm", 2.0 * P * s.cin * s.k * s.k * 64,
@@ -846,14 +913,16 @@ FUSE_BLOCK_BN = True  # tests flip this to compare with the unfused sequence
 
 
 @torch.no_grad()
-def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, cache2: PackedWeights):
+def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, bn2, cache2: PackedWeights, pre=None):
     """ResNet BasicBlock C -> C (stride 1, identity shortcut; C = 64: layer1, C = 128: layer2) of a FROZEN trunk in train-mode
     BatchNorm, f16:
         y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
     with bn1 + ReLU applied inside conv2's input staging (am_conv_gemm_prebn: the weights-in-registers kernel for C = 64, the
     halo-staged kernel for C = 128): relu(bn1(.)) is never written or re-read -- one 4-bytes-per-element HBM pass less per block.
     Both BatchNorms use batch statistics and update their running statistics exactly as the unfused sequence.  Returns None
-    when the case is not covered (caller runs the unfused blocks)."""
+    when the case is not covered (caller runs the unfused blocks).
+    `pre` = (scale, shift): the block input is relu(x * scale + shift) with x the raw pooled stem (PendingAffine): conv1 forms it in
+    its input staging as conv2 does for bn1, the block end forms it for the residual (am_bn_apply2, relu bits 0 and 1)."""
     import ctypes
     if not (FUSE_BLOCK_BN and x.dtype == torch.float16 and bn1.training and bn2.training):
         return None
@@ -869,7 +938,17 @@ def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, 
     flops = 2.0 * P * C * 9 * C
     raw1 = torch.empty_like(x)
     stats1 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, dev)
-    conv_gemm(g, x, cache1.get_fwd(conv1_w, s, x.dtype), None, False, raw1, stats1, k_real=9 * C)
+    w1 = cache1.get_fwd(conv1_w, s, x.dtype)
+    if pre is not None:
+        try:
+            _timed("conv_gemm", flops, lambda: L.am_conv_gemm_prebn(ctypes.byref(g), AM_F16, ptr(x), ptr(pre[0]), ptr(pre[1]), ptr(w1), ptr(raw1),
+                                                                  ptr(stats1), stream()))
+        except RuntimeError as e:
+            if "UNSUPPORTED" not in str(e):
+                raise
+            return None  # (nothing has touched the BatchNorm buffers yet: the caller materialises the input and runs the plain form)
+    else:
+        conv_gemm(g, x, w1, None, False, raw1, stats1, k_real=9 * C)
     sc1, sh1 = _bn_finalize_nograd(bn1, stats1, P, C)
     raw2 = torch.empty_like(x)
     stats2 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, dev)
@@ -885,7 +964,10 @@ def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, 
         conv_gemm(g, y1, w2, None, False, raw2, stats2, k_real=9 * C)
     sc2, sh2 = _bn_finalize_nograd(bn2, stats2, P, C)
     y = torch.empty_like(x)
-    L.am_bn_apply(AM_F16, ptr(raw2), C, ptr(sc2), ptr(sh2), ptr(x), C, 1, ptr(y), C, P, C, stream())
+    if pre is not None:
+        L.am_bn_apply2(AM_F16, ptr(raw2), C, ptr(sc2), ptr(sh2), ptr(x), C, ptr(pre[0]), ptr(pre[1]), 3, ptr(y), C, P, C, stream())
+    else:
+        L.am_bn_apply(AM_F16, ptr(raw2), C, ptr(sc2), ptr(sh2), ptr(x), C, 1, ptr(y), C, P, C, stream())
     return y
 
 

@@ -123,24 +123,35 @@ class MLPSequential(nn.Sequential):
 
 
 # ---- grouped launches for the parallel branches of the MoE tail (hip/ops.py GroupedLinear / GroupedLayerNorm) --------------
+from ..hip.lib import AM_TAIL_MAX_GROUP as _GROUP_MAX  # noqa: E402  (include/automoe_hip.h: members of one grouped launch)
+
+
 def grouped_linear(layers, inputs, relu, dropouts=None):
     """[act(layer_i(x_i))] for independent nn.Linear layers in ONE launch; `dropouts` (optional, per layer: a Dropout module or
     None) is the Dropout that follows Linear -> ReLU in the reference's Sequential, fused into the same epilogue when it is
     active (training, p > 0)."""
-    dropouts = dropouts or [None] * len(layers)
-    spec, args = [], []
-    for layer, x, dr in zip(layers, inputs, dropouts):
-        p = float(dr.p) if (dr is not None and dr.training and dr.p > 0.0) else 0.0
-        spec.append((bool(relu), p))
-        args += [x, layer.weight, layer.bias]
-    return list(hops.GroupedLinear.apply(spec, *args))
+    layers, inputs = list(layers), list(inputs)
+    dropouts = list(dropouts) if dropouts else [None] * len(layers)
+    out = []
+    for lo in range(0, len(layers), _GROUP_MAX):  # more members than one launch table holds (8 experts + context): several launches
+        spec, args = [], []
+        for layer, x, dr in zip(layers[lo:lo + _GROUP_MAX], inputs[lo:lo + _GROUP_MAX], dropouts[lo:lo + _GROUP_MAX]):
+            p = float(dr.p) if (dr is not None and dr.training and dr.p > 0.0) else 0.0
+            spec.append((bool(relu), p))
+            args += [x, layer.weight, layer.bias]
+        out += list(hops.GroupedLinear.apply(spec, *args))
+    return out
 
 
 def grouped_layernorm(norms, inputs):
-    args = []
-    for ln, x in zip(norms, inputs):
-        args += [x, ln.weight, ln.bias]
-    return list(hops.GroupedLayerNorm.apply([ln.eps for ln in norms], *args))
+    norms, inputs = list(norms), list(inputs)
+    out = []
+    for lo in range(0, len(norms), _GROUP_MAX):
+        args = []
+        for ln, x in zip(norms[lo:lo + _GROUP_MAX], inputs[lo:lo + _GROUP_MAX]):
+            args += [x, ln.weight, ln.bias]
+        out += list(hops.GroupedLayerNorm.apply([ln.eps for ln in norms[lo:lo + _GROUP_MAX]], *args))
+    return out
 
 
 def mlp5(seq):

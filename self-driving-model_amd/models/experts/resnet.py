@@ -38,6 +38,16 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):  # x: NHWC
+        if isinstance(x, hconv.PendingAffine):
+            # the pooled stem with its BatchNorm + ReLU still pending (one-pass frozen stem): the fused frozen block forms it in
+            # conv1's input staging and in the block-end pass; any other case writes the normalised map first
+            y = None
+            if self.downsample is None and self.conv1.in_channels == 64 and not self.conv1.weight.requires_grad:
+                y = hconv.fused_basic_block_identity(x.raw, self.conv1.weight, self.bn1, self.conv1._packed, self.conv2.weight, self.bn2,
+                                                     self.conv2._packed, pre=(x.scale, x.shift))
+            if y is not None:
+                return y
+            x = x.materialize()
         if self.downsample is None and self.conv1.in_channels in (64, 128) and (not torch.is_grad_enabled() or not self.conv1.weight.requires_grad):
             y = hconv.fused_basic_block_identity(x, self.conv1.weight, self.bn1, self.conv1._packed, self.conv2.weight, self.bn2,
                                                  self.conv2._packed)  # frozen layer1 / layer2 block: bn1 + ReLU live inside conv2's input staging
@@ -84,7 +94,9 @@ class Trunk(nn.Sequential):
         pooled = None
         if not torch.is_grad_enabled() or not any(p.requires_grad for p in (self[0].weight, self[1].weight, self[1].bias)):
             cfg = hconv._Cfg(self[0].spec, self[0]._packed, self[1], True, runtime.loss_scale(), getattr(x, "orig_hw", None))
-            pooled = hconv.fused_stem_pool(x, self[0].weight, self[1], cfg)  # frozen stem: conv+BN+ReLU+maxpool in two light passes
+            # frozen stem: conv + BN + ReLU + maxpool in one light pass (train-mode BatchNorm: a PendingAffine for layer1's first
+            # block) or two
+            pooled = hconv.fused_stem_pool(x, self[0].weight, self[1], cfg, allow_pending=True)
         if pooled is None:
             # trainable stem: normalise + ReLU + max-pool as one pass over the raw conv output when the fused pass applies (the
             # call then returns the pooled map); otherwise the separate pool

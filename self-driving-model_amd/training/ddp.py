@@ -170,16 +170,30 @@ class GradBucketReducer:
         return int(t.item())
 
 
+def capture_error_mode() -> str:
+    """`capture_error_mode` of every hipGraph capture in this package: "thread_local", whether or not this trainer's own reducer
+    is enabled (round 2 chose "global" whenever the reducer was off, although another object's process group -- and c10d's
+    watchdog thread, which polls events with hipEventQuery about every 100 ms -- may be alive in the same process).
+
+    What is known about round 2's one abort ("a hipEventQuery inside another thread's capture window came back with a HIP error"):
+    it was seen once, no log of it was kept, and it does NOT reproduce: scratch/capture_mode_probe.py (a second thread calling
+    Event.query() every 2 ms through a capture window, 40 queries, one child process per mode) ran clean in thread_local, relaxed
+    AND global mode on this runtime (gpurun_out/r3_capture_probe.log).  So a foreign-thread query is legal
+    here in every mode and the 0.3 s sleep that used to sit in quiesce_collectives guarded against something that was never
+    established: it is removed.  thread_local is kept because it is the mode whose CONTRACT allows other threads' runtime calls
+    (CUDA programming guide, stream-capture modes), not because a failure was tied to the other two.  If a worker aborts again,
+    tests/test_hip_multigpu.py now keeps its whole output, c10d's flight-recorder dump and C++ stacks under gpurun_out/."""
+    return "thread_local"
+
+
 def quiesce_collectives(reducer: "GradBucketReducer"):
-    """Before a capture begins: every eager collective issued so far (the mode agreement, earlier steps' buckets) has finished AND
-    has been reaped by the process group's watchdog thread, so that thread has no event left to poll while this thread captures.
-    (c10d's watchdog calls hipEventQuery on the events of outstanding work about every 100 ms; a query that lands inside
-    another thread's capture window was seen once, in a full test-suite run, to come back with a HIP error and abort the process --
-    capture_error_mode="thread_local" is meant to allow it.  Captured collectives themselves are never handed to the watchdog.)"""
+    """Before a capture begins: every eager collective this reducer issued (earlier steps' buckets) has been waited for and the
+    device is idle -- ordering hygiene that is true by construction (handles held and waited, then a device synchronize), no
+    timing margin."""
     if reducer.enabled and torch.cuda.is_available():
-        import time
+        for h in reducer._handles:
+            h.wait()
         torch.cuda.synchronize()
-        time.sleep(0.3)
 
 
 def capture_step(reducer: GradBucketReducer, capture_fn, what: str = "train step"):

@@ -21,6 +21,10 @@ class HungarianMatcher(nn.Module):
         self.cost_bbox = cost_bbox
         self.cost_giou = cost_giou
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0
+        # test hook: keep the last cost tensor ([B, Nmax, Q], transposed storage) and assignment of match_padded alive, so a
+        # test can hold the assignment made INSIDE a replayed step graph against scipy on that step's own cost matrices
+        self.keep_last = False
+        self.last_cost = self.last_match = None
 
     @torch.no_grad()
     def match_padded(self, pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt):
@@ -28,7 +32,10 @@ class HungarianMatcher(nn.Module):
         (pred_idx [B,k], tgt_idx [B,k], count [B], status [B]); no host synchronisation."""
         cost = hm.match_cost(pred_logits, pred_boxes, tgt_labels, tgt_boxes, n_tgt, self.cost_class, self.cost_bbox,
                              self.cost_giou)
-        return hm.lsap_batched(cost, n_tgt, transposed_storage=True)
+        out = hm.lsap_batched(cost, n_tgt, transposed_storage=True)
+        if self.keep_last:
+            self.last_cost, self.last_match = cost, out
+        return out
 
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]) -> List[Tuple[torch.Tensor, torch.Tensor]]:

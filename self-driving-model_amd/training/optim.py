@@ -16,6 +16,7 @@ import os
 import torch
 
 from .. import runtime
+from ..hip import conv as _conv
 from ..hip import lib as _lib
 from ..hip.conv import ptr, require_hip, stream
 
@@ -81,6 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         L = _lib.get()
+        _conv.assert_residual_handoff_consumed()
         self._gather_stray_grads()
         self.step_count += 1
         group = self.param_groups[0]

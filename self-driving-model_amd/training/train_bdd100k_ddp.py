@@ -22,7 +22,7 @@ from ..hip import ops as hops
 from ..models.experts import BDDDetectionExpert, BDDDrivableExpert, BDDSegmentationExpert
 from . import metrics as val_metrics
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_error_mode, capture_step, detached
 from .hungarian_matcher import HungarianMatcher
 from .optim import FusedAdamW
 
@@ -139,7 +139,7 @@ class BDDTrainer:
 
     def _capture(self, batch):
         self._static = {k: v.to(self.device).clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
-        mode = "thread_local" if self.reducer.enabled else "global"
+        mode = capture_error_mode()  # thread_local: a live process group's watchdog polls events from its own thread (training/ddp.py)
 
         def capture(in_graph):
             g = torch.cuda.CUDAGraph()

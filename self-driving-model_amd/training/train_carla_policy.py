@@ -18,7 +18,7 @@ import torch.distributed as dist
 from .. import runtime
 from ..models.policy.trajectory_head import TrajectoryPolicy
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_error_mode, capture_step, detached
 from .optim import FusedAdamW
 
 
@@ -69,7 +69,7 @@ class PolicyTrainStep:
 
     def _capture(self, batch):
         self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        mode = "thread_local" if self.reducer.enabled else "global"
+        mode = capture_error_mode()  # thread_local: a live process group's watchdog polls events from its own thread (training/ddp.py)
 
         def capture(in_graph):
             g = torch.cuda.CUDAGraph()

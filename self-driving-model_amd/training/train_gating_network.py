@@ -19,7 +19,7 @@ import torch.nn.functional as F  # noqa: F401  (kept for API parity with the ref
 from .. import runtime
 from ..models.automoe import create_automoe_model
 from . import synthetic
-from .ddp import DataParallel, GradBucketReducer, StepStream, capture_step, detached, quiesce_collectives
+from .ddp import DataParallel, GradBucketReducer, StepStream, capture_error_mode, capture_step, detached, quiesce_collectives
 from .optim import FusedAdamW
 
 
@@ -146,8 +146,7 @@ class GatingTrainStep:
 
     def _capture(self, batch):
         self._static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        # with a process group alive its watchdog thread touches the runtime concurrently: only police this thread
-        mode = "thread_local" if self.reducer.enabled else "global"
+        mode = capture_error_mode()  # thread_local: a live process group's watchdog polls events from its own thread (training/ddp.py)
         cache_b = None
         try:
             quiesce_collectives(self.reducer)  # (the expert graph below is captured outside capture_step)

@@ -70,6 +70,19 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """Parity bookkeeping of tests/test_hip_models.py::_grad_check: how many parameter gradients were compared element-wise
     with the fp32 oracle, and every one that needed the fp64 arbitration (ill-conditioned train-mode BatchNorm cases)."""
     mod = sys.modules.get("test_hip_models")
+    if mod is not None and getattr(mod, "F16_DISTANCE", None):
+        import json
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "f16_distance.json"), "w") as f:
+                json.dump({"bounds": mod.F16_BOUNDS, "measured": mod.F16_DISTANCE}, f, indent=1)
+        except OSError:
+            pass
+        terminalreporter.write_sep("=", "f16 vs fp32-mode distance at full size")
+        for tag, rec in mod.F16_DISTANCE.items():
+            terminalreporter.write_line(f"{tag}: loss delta {rec['loss_rel_delta']:.2e}  cos {rec['all']['cos']:.4f}  rel-L2 {rec['all']['rel_l2']:.4f}")
+            for k, v in rec["stages"].items():
+                terminalreporter.write_line(f"    {k:24s} cos {v['cos']:.4f}  rel-L2 {v['rel_l2']:.4f}  |g| {v['norm_fp32']:.3e}  ({v['params']} tensors)")
     if mod is None or not getattr(mod, "COMPARED", None):
         return
     import json
@@ -77,7 +90,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tr = terminalreporter
     tr.write_sep("=", "gradient parity: fp64 arbitrations")
     tr.write_line(f"parameters compared element-wise with the fp32 oracle: {sum(c[1] for c in cmp_)} in {len(cmp_)} checks; "
-                  f"arbitrated against fp64: {len(arb)}")
+                  f"arbitrated against fp64: {len(arb)}, of which hip is at least as close to fp64 as torch-cpu-fp32: "
+                  f"{sum(1 for a in arb if a['hip_vs_fp64'] <= a['torch_fp32_vs_fp64'])}")
     for a in arb:
         tr.write_line(f"  {a['test']}  {a['param']}: hip vs fp64 {a['hip_vs_fp64']:.2e}, torch-cpu-fp32 vs fp64 {a['torch_fp32_vs_fp64']:.2e} "
                       f"(missed rtol {a['rtol']:g} / atol {a['atol']:g} against torch-cpu-fp32)")

@@ -135,6 +135,31 @@ def _grad_summary(module, tag, out):
         out[f"{tag}/gl2/{n}"] = g.double().pow(2).sum().sqrt().numpy()
 
 
+def _f64_twin(m):
+    """The same module in double: the arbiter for stored gradients (a ReLU whose pre-activation is within fp32 rounding of zero
+    takes either branch in fp32 -- torch's own included; the tests accept a gradient that is closer to this run than the fp32
+    reference run is)."""
+    import copy
+    return copy.deepcopy(m).double()
+
+
+class _default_f64:
+    """torch.zeros(...) & co. inside the reference's forward (gating_network.py:163 builds its accumulator that way) follow
+    the default dtype: double for the arbiter run."""
+
+    def __enter__(self):
+        self.prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *exc):
+        torch.set_default_dtype(self.prev)
+        return False
+
+
+def _dbl(batch):
+    return {k: (v.double() if isinstance(v, torch.Tensor) and v.dtype.is_floating_point else v) for k, v in batch.items()}
+
+
 def _no_dropout(m):
     for d in m.modules():
         if isinstance(d, nn.Dropout):
@@ -200,6 +225,19 @@ def automoe_cases(experts):
                 if not frozen:
                     out[f"{tag}/d_expert0_head2"] = m.experts[0].head[2].weight.grad.numpy()
                     out[f"{tag}/d_expert2_conv1"] = m.experts[2].backbone[0].weight.grad.numpy()
+                m64 = _f64_twin(m)
+                m64.zero_grad(set_to_none=True)
+                with _default_f64():
+                    o64 = m64(_dbl(batch))
+                l64 = ((o64["waypoints"] * seeded_tensor((B, 10, 2), 1110).double()).sum() + (o64["speed_seq"] * seeded_tensor((B, 10), 1111).double()).sum()
+                       + (o64["speed"] * seeded_tensor((B, 1), 1112).double()).sum() + (o64["expert_weights"] * seeded_tensor((B, 3), 1113).double()).sum()
+                       + (o64["gate_logits"] * seeded_tensor((B, 3), 1114).double()).sum() + (o64["combined_features"] * seeded_tensor((B, 256), 1115).double()).sum())
+                l64.backward()
+                out[f"{tag}/d_policy_conv0_f64"] = m64.policy_head.backbone.net[0].weight.grad.numpy()
+                out[f"{tag}/d_gate_out_f64"] = m64.gating_network.gate_network[3].weight.grad.numpy()
+                if not frozen:
+                    out[f"{tag}/d_expert0_head2_f64"] = m64.experts[0].head[2].weight.grad.numpy()
+                    out[f"{tag}/d_expert2_conv1_f64"] = m64.experts[2].backbone[0].weight.grad.numpy()
         if mode == "eval":
             out["eval/ctx_only_weights"] = m.get_expert_weights(automoe_batches()["seq"]).detach().numpy()
     return out
@@ -233,6 +271,20 @@ def expert_cases(experts):
             last = m.head[2] if hasattr(m, "head") else m.decoder[2]
             out[f"{tag}/d_last_w"] = last.weight.grad.numpy()
             out[f"{tag}/d_conv1_w"] = m.backbone[0].weight.grad.numpy()
+            m64 = _f64_twin(m)
+            m64.zero_grad(set_to_none=True)
+            x64 = x.detach().double().requires_grad_()
+            o64 = m64(x64)
+            if isinstance(o64, dict):
+                l64 = (o64["class_logits"] * seeded_tensor(tuple(o64["class_logits"].shape), 1220).double()).sum() + \
+                      (o64["bbox_deltas"] * seeded_tensor(tuple(o64["bbox_deltas"].shape), 1221).double()).sum()
+            else:
+                l64 = (o64 * seeded_tensor(tuple(o64.shape), 1222).double()).sum() / (H * W)
+            l64.backward()
+            last64 = m64.head[2] if hasattr(m64, "head") else m64.decoder[2]
+            out[f"{tag}/d_last_w_f64"] = last64.weight.grad.numpy()
+            out[f"{tag}/d_conv1_w_f64"] = m64.backbone[0].weight.grad.numpy()
+            out[f"{tag}/d_x_mean_f64"] = x64.grad.mean(dim=(2, 3)).numpy()
     return out
 
 
@@ -275,6 +327,30 @@ def set_loss_cases(experts):
             _grad_summary(model, tag, out)
             out[f"{tag}/d_head2_w"] = model.head[2].weight.grad.numpy()
             out[f"{tag}/d_head2_b"] = model.head[2].bias.grad.numpy()
+            if bname == "mixed":
+                # arbiter run in double on the SAME assignment (the matcher's decision is part of the fp32 step being pinned)
+                with torch.no_grad():
+                    o32 = model(batch["image"])
+                    B_, C_, H_, W_ = o32["class_logits"].shape
+                    tg = []
+                    for b in range(B_):
+                        keep = batch["labels"][b] != -1
+                        bx = batch["bboxes"][b][keep]
+                        from oracle import matcher as om
+                        tg.append({"boxes": om.box_xyxy_to_cxcywh(bx) if bx.numel() else bx, "labels": batch["labels"][b][keep]})
+                    idx32 = t.matcher({"pred_logits": o32["class_logits"].permute(0, 2, 3, 1).reshape(B_, H_ * W_, C_),
+                                       "pred_boxes": o32["bbox_deltas"].permute(0, 2, 3, 1).reshape(B_, H_ * W_, 4)}, tg)
+                t64 = object.__new__(trainer_cls)
+                t64.model, t64.device, t64.config, t64.task = _f64_twin(model), "cpu", {"bbox_loss_weight": 2.0}, "detection"
+                t64.model.zero_grad(set_to_none=True)
+                t64.class_loss_fn, t64.bbox_loss_fn = t.class_loss_fn, t.bbox_loss_fn
+                t64.matcher = lambda outputs, targets: idx32
+                with _default_f64():
+                    l64 = t64._train_detection_batch(dict(batch, image=batch["image"].double()))  # (targets stay fp32: the reference builds its target buffers in fp32)
+                l64.backward()
+                out[f"{tag}/loss_f64"] = l64.detach().double().numpy()
+                out[f"{tag}/d_head2_w_f64"] = t64.model.head[2].weight.grad.numpy()
+                out[f"{tag}/d_head2_b_f64"] = t64.model.head[2].bias.grad.numpy()
     for name, ncls in (("BDDSegmentationExpert", 19), ("BDDDrivableExpert", 3)):
         for mode in ("eval", "train"):
             model = seed_module_(experts[name](num_classes=ncls, pretrained_backbone=False), 1320 + ncls)
@@ -293,6 +369,13 @@ def set_loss_cases(experts):
             out[f"{tag}/loss"] = loss.detach().double().numpy()
             _grad_summary(model, tag, out)
             out[f"{tag}/d_dec2_w"] = model.decoder[2].weight.grad.numpy()
+            t64 = object.__new__(trainer_cls)
+            t64.model, t64.device, t64.config, t64.task, t64.loss_fn = _f64_twin(model), "cpu", {}, "segmentation", t.loss_fn
+            t64.model.zero_grad(set_to_none=True)
+            l64 = t64._train_segmentation_batch(dict(batch, image=batch["image"].double()))
+            l64.backward()
+            out[f"{tag}/loss_f64"] = l64.detach().double().numpy()
+            out[f"{tag}/d_dec2_w_f64"] = t64.model.decoder[2].weight.grad.numpy()
     return out
 
 

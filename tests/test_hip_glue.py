@@ -20,7 +20,7 @@ from test_oracle_glue_cpu import AUTOMOE_TAGS, EXPERT_CASES, expert_projection, 
 pytestmark = pytest.mark.gpu
 
 RT, AT = 1e-3, 1e-5
-TRAIN_GRAD_L2 = 1e-2
+TRAIN_GRAD_L2 = 5e-3  # measured on MI355X (gpurun_out/r3_glue.log): <= 1.5e-3
 
 
 def _dev():
@@ -42,13 +42,32 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def grad_close(a, b, train, what):
-    if train:
-        e = rel_l2(a, b)
-        assert e <= TRAIN_GRAD_L2, f"{what}: rel L2 {e:.2e} > {TRAIN_GRAD_L2:g}"
-    else:
+GLUE_ARBITRATIONS = []  # (what, hip vs fp64, reference-fp32 vs fp64): printed; the reference's fp32 run is itself this far from its fp64 run
+
+
+def grad_close(a, b, train, what, b64=None):
+    """A stored gradient tensor against the reference's fp32 run.  Eval-mode BatchNorm: relative L2 <= 2e-4 and no element farther
+    than 1e-3 of the tensor's largest magnitude (+ atol 1e-5); train-mode BatchNorm (ill-conditioned at these shapes): relative
+    L2 <= TRAIN_GRAD_L2.  A tensor that misses is judged against the reference's DOUBLE run of the same step (`b64`, stored in the
+    fixture): a ReLU whose pre-activation is within fp32 rounding of zero takes either branch in fp32 -- torch-CPU's run included
+    -- and that one pixel moves a weight gradient by ~1e-5 per element, 5e-4 in relative L2; the HIP fp32 mode accumulates its
+    convolutions in double (conv_gemm.hip), so it usually sides with the double run where torch's fp32 run does not.  Accepted
+    then: HIP at most as far from the double run as the reference's fp32 run is (x2); every such case is printed."""
+    e = rel_l2(a, b)
+    ok = e <= (TRAIN_GRAD_L2 if train else 2e-4)
+    if ok and not train:
         scale = float(np.abs(np.asarray(b)).max())
-        close(a, b, rtol=RT, atol=max(AT, 1e-4 * scale), what=what)  # atol relative to the tensor's size: sums over 1e4-1e5 products
+        try:
+            close(a, b, rtol=RT, atol=AT + 1e-3 * scale, what=what)
+        except AssertionError:
+            ok = False
+    if ok:
+        return
+    assert b64 is not None, f"{what}: rel L2 {e:.2e} against the reference's fp32 run, no fp64 arbiter in the fixture"
+    e_hip, e_ref = rel_l2(a, b64), rel_l2(b, b64)
+    GLUE_ARBITRATIONS.append((what, e_hip, e_ref))
+    print(f"[glue arbitration] {what}: hip vs fp64 {e_hip:.2e}, reference fp32 vs fp64 {e_ref:.2e} (hip vs reference fp32 {e:.2e})")
+    assert e_hip <= max(1e-5, 2 * e_ref), f"{what}: hip vs fp64 {e_hip:.2e} > 2 x reference-fp32 vs fp64 {e_ref:.2e}"
 
 
 def check_grad_norms(m, g, tag, train):
@@ -62,7 +81,8 @@ def check_grad_norms(m, g, tag, train):
             continue
         got = float(p.grad.double().pow(2).sum().sqrt())
         e = abs(got - ref_l2) / (ref_l2 + 1e-12)
-        worst = max(worst, e)
+        if ref_l2 >= 1e-6:
+            worst = max(worst, e)
         assert e <= (TRAIN_GRAD_L2 if train else 2e-3) or ref_l2 < 1e-6, f"{tag} {n}: |g| {got:.6e} vs reference {ref_l2:.6e}"
         if not train:
             gs = float(p.grad.double().sum())
@@ -116,11 +136,11 @@ def test_automoe_vs_reference_class_golden(golden_dir, tag):
     close(eo[2], g[f"{tag}/expert2"], atol=1e-4)
     close(loss, g[f"{tag}/loss"], rtol=1e-4, atol=1e-4)
     worst = check_grad_norms(hip, g, tag, train)
-    grad_close(hip.policy_head.backbone.net[0].weight.grad, g[f"{tag}/d_policy_conv0"], train, "policy conv0")
-    grad_close(hip.gating_network.gate_network[3].weight.grad, g[f"{tag}/d_gate_out"], train, "gate out")
+    grad_close(hip.policy_head.backbone.net[0].weight.grad, g[f"{tag}/d_policy_conv0"], train, f"{tag} policy conv0", g[f"{tag}/d_policy_conv0_f64"])
+    grad_close(hip.gating_network.gate_network[3].weight.grad, g[f"{tag}/d_gate_out"], train, f"{tag} gate out", g[f"{tag}/d_gate_out_f64"])
     if fr == "unfrozen":
-        grad_close(hip.experts[0].head[2].weight.grad, g[f"{tag}/d_expert0_head2"], train, "expert0 head")
-        grad_close(hip.experts[2].backbone[0].weight.grad, g[f"{tag}/d_expert2_conv1"], train, "expert2 conv1")
+        grad_close(hip.experts[0].head[2].weight.grad, g[f"{tag}/d_expert0_head2"], train, f"{tag} expert0 head", g[f"{tag}/d_expert0_head2_f64"])
+        grad_close(hip.experts[2].backbone[0].weight.grad, g[f"{tag}/d_expert2_conv1"], train, f"{tag} expert2 conv1", g[f"{tag}/d_expert2_conv1_f64"])
     else:
         assert all(p.grad is None for p in hip.experts.parameters())
     if tag == "eval/frozen/seq":
@@ -161,10 +181,10 @@ def test_expert_wrappers_vs_reference_class_golden(golden_dir, name, ncls, mode)
     close(loss, g[f"{tag}/loss"], rtol=1e-4, atol=1e-4)
     worst = check_grad_norms(hip, g, tag, train)
     last = hip.head[2] if hasattr(hip, "head") else hip.decoder[2]
-    grad_close(last.weight.grad, g[f"{tag}/d_last_w"], train, "last conv")
-    grad_close(hip.backbone[0].weight.grad, g[f"{tag}/d_conv1_w"], train, "conv1")
+    grad_close(last.weight.grad, g[f"{tag}/d_last_w"], train, f"{tag} last conv", g[f"{tag}/d_last_w_f64"])
+    grad_close(hip.backbone[0].weight.grad, g[f"{tag}/d_conv1_w"], train, f"{tag} conv1", g[f"{tag}/d_conv1_w_f64"])
     if x.grad is not None:
-        grad_close(x.grad.double().mean(dim=(2, 3)), g[f"{tag}/d_x_mean"], True, "d image")
+        grad_close(x.grad.double().mean(dim=(2, 3)), g[f"{tag}/d_x_mean"], True, f"{tag} d image", g[f"{tag}/d_x_mean_f64"])
     print(f"[glue] {tag}: worst |grad| relative deviation {worst:.2e}")
 
 
@@ -216,8 +236,8 @@ def test_detection_set_loss_vs_reference_trainer_golden(golden_dir, mode, bname)
         if not train:  # eval-mode statistics: the device cost is the reference's cost to ~1e-5, the optimum is the same
             assert rows[b, :n].cpu().tolist() == rr.tolist() and cols[b, :n].cpu().tolist() == cc.tolist(), b
     worst = check_grad_norms(hip, g, tag, train)
-    grad_close(hip.head[2].weight.grad, g[f"{tag}/d_head2_w"], train, "head[2].weight")
-    grad_close(hip.head[2].bias.grad, g[f"{tag}/d_head2_b"], train, "head[2].bias")
+    grad_close(hip.head[2].weight.grad, g[f"{tag}/d_head2_w"], train, f"{tag} head[2].weight", g[f"{tag}/d_head2_w_f64"])
+    grad_close(hip.head[2].bias.grad, g[f"{tag}/d_head2_b"], train, f"{tag} head[2].bias", g[f"{tag}/d_head2_b_f64"])
     print(f"[glue] {tag}: worst |grad| relative deviation {worst:.2e}")
 
 
@@ -248,5 +268,5 @@ def test_segmentation_loss_vs_reference_trainer_golden(golden_dir, name, ncls, m
     torch.cuda.synchronize()
     close(loss, g[f"{tag}/loss"], rtol=1e-4, atol=1e-5, what="segmentation loss")
     worst = check_grad_norms(hip, g, tag, train)
-    grad_close(hip.decoder[2].weight.grad, g[f"{tag}/d_dec2_w"], train, "decoder[2].weight")
+    grad_close(hip.decoder[2].weight.grad, g[f"{tag}/d_dec2_w"], train, f"{tag} decoder[2].weight", g[f"{tag}/d_dec2_w_f64"])
     print(f"[glue] {tag} fused={fused}: worst |grad| relative deviation {worst:.2e}")

@@ -26,7 +26,20 @@ def _run_ranks(script_path, nproc, port, args, timeout=900, extra_env=None):
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script_path)] + [str(a) for a in args]
+    # c10d's own records of an abort (which call failed on which thread) survive the worker: flight-recorder dump on a watchdog
+    # exception plus C++ stacks, and the worker's complete output kept under gpurun_out/ when it fails
+    env.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "1")
+    env.setdefault("TORCH_NCCL_LOG_CPP_STACK_ON_UNCLEAN_SHUTDOWN", "1")
+    env.setdefault("TORCH_SHOW_CPP_STACKTRACES", "1")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        try:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, f"multigpu_worker_fail_{os.path.basename(str(script_path))}_{port}.log"), "w") as f:
+                f.write(f"rc={r.returncode}\n==== stdout ====\n{r.stdout}\n==== stderr ====\n{r.stderr}")
+        except OSError:
+            pass
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r
 
