@@ -185,8 +185,12 @@ def main():
         hconv.TIMER = hconv.KernelTimer()
         from self_driving_model_amd.hip import lib as hlib
         hlib.CALL_COUNTS = {}
+        # the in-kernel cycle stamps live in a diagnostic instantiation of conv_ring16_k, selected for these two eager steps only
+        old_diag = hconv._L().am_set_tuning(hlib.AM_TUNE_RING_DIAG, 1)
         for _ in range(2):
             run()
+        torch.cuda.synchronize()
+        hconv._L().am_set_tuning(hlib.AM_TUNE_RING_DIAG, old_diag)
         calls, hlib.CALL_COUNTS = hlib.CALL_COUNTS, None
         tail_prefixes = ("am_linear", "am_layernorm", "am_moe_tail", "am_gate", "am_dropout")
         out["moe_tail"] = {"grouped": bool(model.group_tail),
@@ -205,7 +209,8 @@ def main():
             hconv._L().am_diag_ring_clock(clk, hconv.stream())
             if clk[1] > 0 and clk[2] > 0:
                 ghz = clk[0] / (clk[1] * 10.0)  # cycles per ns
-                in_kernel = {"clock_ghz": round(ghz, 3), "cycles_per_kstep": round(clk[0] / clk[2], 1), "mfma_floor_cycles_per_kstep": 1024,
+                in_kernel = {"kernel": "conv_ring16_k<256,256,2,4> (diagnostic instantiation: the stride-2 entries / policy conv4 launches it still gets)",
+                             "clock_ghz": round(ghz, 3), "cycles_per_kstep": round(clk[0] / clk[2], 1), "mfma_floor_cycles_per_kstep": 1024,
                              "peak_at_clock_tflops": round(PEAK_F16_TFLOPS * ghz / 2.4, 1), "ksteps": int(clk[2]),
                              "prologue_cycles": int(clk[3]), "epilogue_cycles": int(clk[4])}
         except Exception as e:  # noqa: BLE001
@@ -216,21 +221,31 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         fam = summ.get("conv_gemm", {"flops": 0.0, "ms": 1.0, "launches": 0})
         fam_ach = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the committed
-        # figure comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this command (scratch/prof_r02.sh,
-        # FETCH_SIZE doubled per the gfx950 correction; the per-dispatch counter rows are kept in the JSON).  Algorithmic bytes
-        # (input + weights + output, each once) of the 25 forward launches of the 4a step average 105.6 MB.
-        traffic, traffic_src, alg_bytes = None, None, None
+        # HBM-side bytes per launch and the MFMA-busy share of the dominant kernel: PMC counters cannot be read from inside this
+        # process; the figures come from separate `rocprofv3 --pmc` passes of this command (scratch/prof_r03.sh -> profiles/r03/
+        # pmc_conv_kernels.json: FETCH_SIZE doubled per the gfx950 correction, raw per-dispatch rows inside).  They are reported
+        # under `static` with the identity of what they were measured on, and `roofline.traffic` carries the number only while
+        # the kernel's source file in this tree is byte-identical to the one profiled (sha256) -- otherwise null.
+        traffic, static = None, {"measured_in_run": False, "source": "profiles/r03/pmc_conv_kernels.json", "stale": True}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_dominant_kernel.json")))
-            if dom_name.startswith("conv_ring16_k<256,256") and args.batch == 32:
-                traffic, traffic_src = int(pmc["hbm_bytes_per_launch"]), "profiles/r02_pmc_dominant_kernel.json (raw per-dispatch counters inside)"
-                alg_bytes = float(pmc["algorithmic_bytes_per_launch"])
-        except Exception:  # noqa: BLE001
-            pass
+            import hashlib
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_conv_kernels.json")))
+            ent = next((v for k, v in pmc["kernels"].items() if dom_name.split("<")[0].split(" ")[0] == k.split("<")[0]), None)
+            if ent is not None:
+                cur = hashlib.sha256(open(os.path.join(ROOT, ent["source"]), "rb").read()).hexdigest()
+                static.update({"kernel": dom_name, "kernel_source": ent["source"], "kernel_source_sha256_profiled": ent["source_sha256"],
+                               "stale": cur != ent["source_sha256"] or args.batch != pmc.get("batch"),
+                               "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "mfma_busy_frac": ent.get("mfma_busy_frac"),
+                               "share_of_wave_cycles": ent.get("share_of_wave_cycles")})
+                if not static["stale"] and ent.get("hbm_bytes_per_launch"):
+                    traffic = int(ent["hbm_bytes_per_launch"])
+        except Exception as e:  # noqa: BLE001
+            static["error"] = repr(e)[:120]
+        # algorithmic bytes of the dominant kernel's launches (input + weights + output, each once, f16), from this run's launch list
+        alg_bytes = dom.get("bytes", 0.0) / max(dom["launches"], 1) if dom.get("bytes") else None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": alg_bytes,
+                           "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                           "algorithmic_bytes_per_launch": alg_bytes, "static": static,
                            "kernel": dom_name, "in_kernel": in_kernel, "launches_per_step": dom["launches"] // 2,
                            "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                            "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
@@ -267,12 +282,15 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        try:  # the GPU test session's gradient-parity bookkeeping (tests/conftest.py), as last committed under profiles/
-            pa = json.load(open(os.path.join(ROOT, "profiles", "r02_parity_arbitrations.json")))
-            out["parity"] = {"gradients_compared_elementwise": sum(c["parameters"] for c in pa["checks"]),
-                             "arbitrations": len(pa["arbitrations"]),
-                             "strict_checks_without_arbitration": sum(1 for c in pa["checks"] if c["test"].startswith("strict/")),
-                             "source": "profiles/r02_parity_arbitrations.json"}
+        try:  # the GPU test session's parity bookkeeping (tests/conftest.py), as last committed under profiles/: NOT measured in this run
+            pa = json.load(open(os.path.join(ROOT, "profiles", "r03", "parity_arbitrations.json")))
+            arb = pa["arbitrations"]
+            out["static_parity"] = {"measured_in_run": False, "source": "profiles/r03/parity_arbitrations.json",
+                                    "gradients_compared_elementwise": sum(c["parameters"] for c in pa["checks"]),
+                                    "arbitrations": len(arb),
+                                    "arbitrations_where_hip_is_at_least_as_close_to_fp64_as_torch_cpu_fp32":
+                                        sum(1 for a in arb if a["hip_vs_fp64"] <= a["torch_fp32_vs_fp64"]),
+                                    "strict_checks_without_arbitration": sum(1 for c in pa["checks"] if c["test"].startswith("strict/"))}
         except Exception:  # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)

@@ -708,6 +708,8 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_PATCH_WGRAD_MIN_TILES */ 512,
     /* AM_TUNE_PATCH_WGRAD_C128 */ 1,
     /* AM_TUNE_DUO_MFMA16 */ 1,
+    /* AM_TUNE_BAND_MIN_TILES */ 200,
+    /* AM_TUNE_RING_DIAG */ 0,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }
@@ -726,6 +728,8 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
 
 int am_conv_halo_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                      double* stats, hipStream_t s);  // conv_halo.hip
+int am_conv_band16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
+                       double* stats, hipStream_t s);  // conv_band16.hip
 int am_conv_halo_pre_f16(const am_conv_geom* g, const void* x, const float* pre_scale, const float* pre_shift, const void* w,
                          const float* bias, int relu, const void* res, void* y, double* stats, hipStream_t s);  // conv_halo.hip
 
@@ -765,6 +769,9 @@ extern "C" int am_conv_gemm(const am_conv_geom* g, int dtype, const void* x, con
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // 3x3 / stride-1 layers with 64 < N <= 128 (layer2 and its dgrad): halo-staged patch instead of nine gathers
     rc = am_conv_halo_f16(g, x, w, bias, relu, nullptr, y, stats, s);
+    if (rc != AM_ERR_UNSUPPORTED) return rc;
+    // 3x3 / stride-1 layers with N = 256 / 512 on maps up to 128 pixels wide (layers 3-4, the heads, their dgrads): row-band halo
+    rc = am_conv_band16_f16(g, x, w, bias, relu, nullptr, y, stats, s);
     if (rc != AM_ERR_UNSUPPORTED) return rc;
     // N > 64: the LDS-DMA ring kernels (conv_ring.hip) win at every M; N <= 64 with a large M (policy layers, dgrads
     // into 64 channels) stays on the register-staged kernel
@@ -888,6 +895,8 @@ extern "C" int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x,
   rc = am_conv3x3_c64n64_duo_f16(g, x, w, bias, relu, res, y, nullptr, s);
   if (rc != AM_ERR_UNSUPPORTED) return rc;
   rc = am_conv_halo_f16(g, x, w, bias, relu, res, y, nullptr, s);
+  if (rc != AM_ERR_UNSUPPORTED) return rc;
+  rc = am_conv_band16_f16(g, x, w, bias, relu, res, y, nullptr, s);
   if (rc != AM_ERR_UNSUPPORTED) return rc;
   return am_conv_ring_f16(g, x, w, bias, relu, res, y, nullptr, s);
 }

@@ -372,20 +372,21 @@ class KernelTimer:
     `flops` is the ALGORITHMIC count of the launch, 2*M*K*N with the real (unpadded) K."""
 
     def __init__(self):
-        self.records = []  # (kind, flops, ev0, ev1, kernel)
+        self.records = []  # (kind, flops, ev0, ev1, kernel, algorithmic bytes)
 
     def summary(self, by: str = "kind"):
         """Totals per launch kind ("conv_gemm" / "conv_dgrad" / "conv_wgrad") or, with by="kernel", per kernel the library's
         dispatcher actually launched (am_conv_last_variant)."""
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1, kernel in self.records:
+        for kind, flops, e0, e1, kernel, nbytes in self.records:
             # input-gradient launches of a forward kernel are listed apart: the one-launch stride-2 form executes 16/9 of its
             # algorithmic FLOPs (structural zeros in the 2x2-block weight matrix), a forward launch exactly its own
             name = kernel + " [dgrad]" if kind == "conv_dgrad" else kernel
-            d = out.setdefault(kind if by == "kind" else name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d = out.setdefault(kind if by == "kind" else name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -393,10 +394,11 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 CONV_KERNEL_NAMES = {1: "conv_ring_k<256,256,2,4>", 2: "conv_ring_k<256,128,4,2>", 3: "conv3x3_c64n64_duo_k", 6: "conv_gemm2_k", 8: "conv_gemm_k",
                      9: "conv_s2d_k", 10: "conv_s2d_pool_k", 11: "conv_ring16_k<256,256,2,4>", 12: "conv_ring16_k<256,128,4,2>",
-                     16: "conv_halo_k"}
+                     16: "conv_halo_k", 18: "conv_band16_k"}
 
 
-def _timed(kind: str, flops: float, fn):
+def _timed(kind: str, flops: float, fn, nbytes: float = 0.0):
+    """`nbytes`: ALGORITHMIC bytes of the launch (input + weights + output, each once) where the caller knows them."""
     if TIMER is None:
         fn()
         return
@@ -404,14 +406,16 @@ def _timed(kind: str, flops: float, fn):
     e0.record()
     fn()
     e1.record()
-    TIMER.records.append((kind, flops, e0, e1, CONV_KERNEL_NAMES.get(_L().am_conv_last_variant(), "?") if kind != "conv_wgrad" else "weight gradients (wgrad_ring_k, conv_wgrad_k, conv_s2d_wgrad_k, conv_patch_wgrad_k)"))
+    TIMER.records.append((kind, flops, e0, e1, CONV_KERNEL_NAMES.get(_L().am_conv_last_variant(), "?") if kind != "conv_wgrad" else "weight gradients (wgrad_ring_k, conv_wgrad_k, conv_s2d_wgrad_k, conv_patch_wgrad_k)", nbytes))
 
 
 def conv_gemm(g: ConvGeom, x, wp, bias, relu: bool, y, stats=None, k_real: Optional[int] = None, kind: str = "conv_gemm"):
     import ctypes
     flops = 2.0 * g.B * g.MH * g.MW * (k_real if k_real is not None else g.ntaps * g.krun) * g.N
+    es = y.element_size()
+    nbytes = float(es) * (g.B * g.IH * g.IW * g.krun + g.N * g.ntaps * g.krun + g.B * g.MH * g.MW * g.N)
     _timed(kind, flops, lambda: _L().am_conv_gemm(ctypes.byref(g), dt_code(y.dtype), ptr(x), ptr(wp), ptr(bias), int(relu),
-                                                  ptr(y), ptr(stats), stream()))
+                                                  ptr(y), ptr(stats), stream()), nbytes)
 
 
 def conv_wgrad_oihw(g: ConvGeom, x, dy, scale: float, w_param, s: "ConvSpec"):
@@ -799,7 +803,6 @@ def conv_bn_act(x, w, b, bn, relu: bool, residual, cfg: _Cfg, training: bool):
     return ConvBnAct.apply(x, w, b, gamma, beta, residual, cfg, training)
 
 
-@torch.no_grad()
 STEM_ONE_PASS = os.environ.get("AUTOMOE_STEM_ONE_PASS", "1") != "0"  # tests flip this to compare with the two-pass form
 
 
@@ -818,6 +821,7 @@ class PendingAffine:
         return y
 
 
+@torch.no_grad()
 def fused_stem_pool(x, conv_w, bn, cfg: _Cfg, allow_pending: bool = False):
     """ResNet stem for a FROZEN trunk in train-mode BatchNorm: conv7x7/s2 -> BN(batch statistics, running stats
     updated) -> ReLU -> MaxPool(3,2,1) without the raw conv output or the normalised map ever reaching HBM.

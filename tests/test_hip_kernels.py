@@ -555,6 +555,74 @@ def test_conv_halo_kernel_vs_torch_and_ring_kernel(case):
     assert float(y[..., cout:].abs().sum()) == 0.0  # pad channels of the pixel stride stay zero
 
 
+@pytest.mark.parametrize("case", [(256, 256, 2, 45, 80), (512, 512, 2, 23, 40), (512, 256, 3, 23, 40), (256, 256, 2, 18, 37), (128, 256, 1, 31, 120),
+                                  (64, 512, 2, 15, 16)])
+def test_conv_band16_kernel_vs_torch_and_ring_kernel(case):
+    """3x3 / stride-1 layers with N = 256 / 512 on maps up to 128 pixels wide (ResNet layers 3-4, the 512 -> 256 heads, their
+    input gradients): the row-band halo kernel conv_band16_k (conv_band16.hip; forced for small grids through
+    AM_TUNE_BAND_MIN_TILES) against torch and against the gather kernels it replaces.  Covered: the two 720p shapes (45 x 80:
+    three-row bands; 23 x 40: six-row bands whose 16-pixel fragments wrap from one band row to the next, last band with a row
+    below the image), widths that are no multiple of 8, a two-row band at the maximum width, a band taller than the image,
+    Cin of 2 / 4 / 8 / 16 chunks, one and two N tiles, BatchNorm statistics (dead tile rows excluded), bias + ReLU and residual
+    epilogues, the input-gradient geometry."""
+    import ctypes
+    from self_driving_model_amd.hip import conv as hc
+    from self_driving_model_amd.hip import lib
+    L = lib.get()
+    cin, cout, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).half().float()
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g).half().float()
+    s = hc.ConvSpec(cin, cout, 3, 1, 1)
+    geom = hc.fwd_geom(s, B, H, W, cin, cout, 2)
+    xd, wp = nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16)
+    yr = F.conv2d(x, w, padding=1)
+    outs = {}
+    for min_tiles, kernel in ((1, "conv_band16_k"), (1 << 30, None)):
+        old = L.am_set_tuning(lib.AM_TUNE_BAND_MIN_TILES, min_tiles)
+        try:
+            y = torch.zeros(B, H, W, cout, dtype=torch.float16, device=_dev())
+            stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
+            hc.conv_gemm(geom, xd, wp, None, False, y, stats)
+            name = launched_kernel(kernel, what=f"band16 {case}")
+            assert kernel is not None or name != "conv_band16_k"
+            y2 = torch.zeros_like(y)
+            hc.conv_gemm(geom, xd, wp, b.to(_dev()), True, y2, None)
+            y3 = torch.zeros_like(y)
+            try:
+                L.am_conv_gemm_res(ctypes.byref(geom), hc.dt_code(torch.float16), hc.ptr(xd), hc.ptr(wp), hc.ptr(b.to(_dev())),
+                                   hc.ptr(nhwc(r, torch.float16)), 1, hc.ptr(y3), hc.stream())
+                y1 = torch.zeros_like(y)
+                hc.conv_gemm(geom, xd, wp, b.to(_dev()), False, y1, None)
+                torch.cuda.synchronize()
+                assert torch.equal(y3, torch.relu(y1.float() + nhwc(r, torch.float16).float()).half()), "residual epilogue differs from the two-pass sequence"
+            except RuntimeError as e:
+                assert "UNSUPPORTED" in str(e) and kernel is None
+                y3 = None
+            (gd, taps), = hc.dgrad_plans(s, B, H, W, cin, cout, 2)
+            dx = torch.zeros(B, H, W, cin, dtype=torch.float16, device=_dev())
+            hc.conv_gemm(gd, nhwc(r, torch.float16), hc.pack_dgrad(w.to(_dev()), taps, torch.float16, cout), None, False, dx, None)
+            dg_name = launched_kernel(None, what=f"band16 dgrad {case}")
+            torch.cuda.synchronize()
+            outs[min_tiles] = (y, stats.view(16, 2, cout).sum(0).cpu(), y2, y3, dx, dg_name)
+        finally:
+            L.am_set_tuning(lib.AM_TUNE_BAND_MIN_TILES, old)
+    y, st, y2, y3, dx, dg_name = outs[1]
+    assert (dg_name == "conv_band16_k") == (cin % 256 == 0), dg_name  # the dgrad's N is the layer's Cin
+    close(nchw(y, cout), yr, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(st[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=0.5)
+    np.testing.assert_allclose(st[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
+    close(nchw(y2, cout), F.relu(yr + b.view(1, -1, 1, 1)), rtol=3e-3, atol=3e-3)
+    if y3 is not None:
+        close(nchw(y3, cout), F.relu(yr + b.view(1, -1, 1, 1) + r), rtol=3e-3, atol=4e-3)
+    close(nchw(dx, cin), F.conv_transpose2d(r, w, padding=1), rtol=3e-3, atol=4e-3)
+    yo, sto, y2o, y3o, dxo, _ = outs[1 << 30]
+    assert rel_err(y, yo) < 2e-3 and rel_err(dx, dxo) < 2e-3 and rel_err(y2, y2o) < 2e-3
+    np.testing.assert_allclose(st.numpy(), sto.numpy(), rtol=1e-4, atol=0.05)
+
+
 @pytest.mark.parametrize("spec", [(64, 7, 3), (32, 5, 2)])
 def test_first_layer_s2d_patch_kernel_and_fused_bn_relu(spec):
     """Large first-layer problems run the weights-stationary s2d kernel (conv_s2d.hip).  Mode 0 (raw + statistics) is

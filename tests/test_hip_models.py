@@ -587,7 +587,7 @@ def test_frozen_stem_one_pass_matches_two_pass_and_unfused(shape, first_block):
     with torch.no_grad():
         ref[1].weight[::5] *= -1.0  # negative gammas: min-pooling channels
         ref[1].weight[7] = 0.0     # and a dead one
-    x = seeded_tensor(shape, 80)
+    x = seeded_tensor((shape[0], 3, shape[1], shape[2]), 80)
 
     def trunk():
         t = Trunk()
@@ -1579,9 +1579,16 @@ def _grad_vector(params):
     return torch.cat([p.grad.detach().flatten().float() for p in params if p.grad is not None])
 
 
-# Bounds of the full-size f16-vs-fp32-mode checks: 2x the distance measured on MI355X (profiles/r03_f16_distance.json), not a guess.
-F16_BOUNDS = {"cfg2": {"loss": 2e-3, "cos": 0.97, "rel_l2": 0.3}, "cfg4b": {"loss": 2e-3, "cos": 0.97, "rel_l2": 0.3},
-              "cfg3": {"loss": 2e-3, "cos": 0.97, "rel_l2": 0.3}}
+# Bounds of the full-size f16-vs-fp32-mode checks: 2x the distance measured on MI355X (profiles/r03/f16_distance.json), not a guess.
+# Measured (round 3): cfg2 all-parameter rel-L2 0.0108 / cosine 0.9999, worst stage (stem) 0.172; 4b 0.0199 / 0.9998, worst stage 0.170;
+# cfg3 (B = 8, set loss) 0.180 / 0.9838, worst stage 0.318; loss deltas 2e-6, 3e-7, 3.5e-6.  Per stage the distance is BORN in the
+# last trunk stage and grows backwards: head 0.1 %, layer4 7 %, layer3 14 %, layer2 16 %, layer1 17 %, stem 17 % (cfg2) -- every
+# train-mode BatchNorm backward subtracts mean(dz) and xhat * mean(dz * xhat) from gradients that were STORED in f16 (2^-11 each), and
+# what is left after the cancellation carries that rounding at a few per cent; the head, the MoE tail and the policy heads (no
+# BatchNorm behind them) stay at 0.1-3 %.
+F16_BOUNDS = {"cfg2": {"loss": 1e-5, "cos": 1 - 2e-4, "rel_l2": 0.022, "stage_rel_l2": 0.35},
+              "cfg4b": {"loss": 1e-5, "cos": 1 - 4e-4, "rel_l2": 0.04, "stage_rel_l2": 0.34},
+              "cfg3": {"loss": 1e-5, "cos": 1 - 0.033, "rel_l2": 0.36, "stage_rel_l2": 0.64}}
 F16_DISTANCE = {}  # tag -> measured f16-vs-fp32-mode distances of a full-size step (written to gpurun_out/f16_distance.json by conftest)
 
 
@@ -1657,6 +1664,7 @@ def test_full_size_drivable_expert_train_step_b16_720p():
     assert rec["loss_rel_delta"] < F16_BOUNDS["cfg2"]["loss"], rec["loss_rel_delta"]
     cos, l2 = rec["all"]["cos"], rec["all"]["rel_l2"]
     assert cos > F16_BOUNDS["cfg2"]["cos"] and l2 < F16_BOUNDS["cfg2"]["rel_l2"], (cos, l2)
+    assert max(v["rel_l2"] for v in rec["stages"].values()) < F16_BOUNDS["cfg2"]["stage_rel_l2"], rec["stages"]
     m.load_state_dict(sd0)
     m.zero_grad(set_to_none=True)
     with runtime.precision(torch.float16):
@@ -1705,6 +1713,7 @@ def test_full_size_automoe_unfrozen_train_step_b32_720p():
     assert rec["loss_rel_delta"] < F16_BOUNDS["cfg4b"]["loss"], rec["loss_rel_delta"]
     cos, l2 = rec["all"]["cos"], rec["all"]["rel_l2"]
     assert cos > F16_BOUNDS["cfg4b"]["cos"] and l2 < F16_BOUNDS["cfg4b"]["rel_l2"], (cos, l2)
+    assert max(v["rel_l2"] for v in rec["stages"].values()) < F16_BOUNDS["cfg4b"]["stage_rel_l2"], rec["stages"]
     m.load_state_dict(sd0)
     m.zero_grad(set_to_none=True)
     with runtime.precision(torch.float16):
@@ -1753,6 +1762,7 @@ def test_full_size_detection_expert_hungarian_train_step_b8_720p():
     # and the head's gradient see a different target set: the bound is on the measured distance, recorded above)
     assert rec["loss_rel_delta"] < F16_BOUNDS["cfg3"]["loss"], rec["loss_rel_delta"]
     assert rec["all"]["cos"] > F16_BOUNDS["cfg3"]["cos"] and rec["all"]["rel_l2"] < F16_BOUNDS["cfg3"]["rel_l2"], rec["all"]
+    assert max(v["rel_l2"] for v in rec["stages"].values()) < F16_BOUNDS["cfg3"]["stage_rel_l2"], rec["stages"]
     m.load_state_dict(sd0)
     m.zero_grad(set_to_none=True)
     with runtime.precision(torch.float16):
@@ -1764,7 +1774,8 @@ def test_full_size_detection_expert_hungarian_train_step_b8_720p():
         # the LAST replay's cost matrices and assignment (graph-pool tensors the matcher kept a reference to)
         cost = tr.matcher.last_cost.float().cpu().numpy()  # [B, Nmax, Q]: cost[b, j, q]
         rows, cols, count, status = (t.cpu() for t in tr.matcher.last_match)
-    assert all(np.isfinite(losses)) and losses[-1] < losses[1] and losses[-1] < 0.9 * max(losses), losses
+    # (the box term is an L1 distance in pixels: hundreds at the start; every step must bring the loss down)
+    assert all(np.isfinite(losses)) and all(b_ < a_ for a_, b_ in zip(losses, losses[1:])), losses
     assert int(tr.optimizer.skipped) == 0
     n_tgt = (b["labels"] != -1).sum(dim=1).cpu().tolist()
     assert count.tolist() == n_tgt and status.tolist() == [0] * B
@@ -1803,7 +1814,7 @@ def test_full_size_automoe_inference_b64_matches_its_b16_quarters():
                 worst[k] = max(worst.get(k, 0.0), float((a - bb).abs().max() / (bb.abs().max() + 1e-12)))
     print("[cfg5] worst B=64 vs B=16-quarter deviation (max abs / max |ref|): " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     for k, v in worst.items():
-        assert v < 2e-2, (k, v)  # f16 rounding through ~20 layers where the two batch sizes take different kernels (measured: see the print)
+        assert v < 1e-4, (k, v)  # measured on MI355X: <= 1.4e-5 (the trunk's per-image results are the same bits; the fp32 MoE tail sums rows in another order)
     w = full["expert_weights"]
     assert torch.allclose(w.sum(dim=1), torch.ones(64), atol=1e-4) and bool((w >= 0).all())
 
