@@ -136,7 +136,8 @@ int am_conv_last_variant(void);
  * compares two).  The only mutable state the library keeps besides the per-thread am_conv_last_variant() record.  Set before
  * launching; returns the previous value (AM_ERR_ARG for an unknown key).
  *   AM_TUNE_RING   0: conv_ring_k (v_mfma_f32_32x32x16_f16), 1: conv_ring16_k (16x16x32, transposed product, pieces issued as a
- *                  block), 2 (default): the same with static issue priority for waves 4-7, 3: pieces placed by wave age.
+ *                  block), 2: the same with static issue priority for waves 4-7, 3: pieces placed by wave age, 4 (default): fragment
+ *                  reads and pieces interleaved with the MFMAs of their half K-step.
  *   AM_TUNE_RING128_MIN_TILES   fewest 256x128 tiles (M/256 * N/128) for which conv_ring_k<256,128> is dispatched.
  *   AM_TUNE_WGRAD_RING   1: wgrad_ring_k where its shape conditions hold, 2: the same with v_mfma_f32_16x16x32_f16 on its
  *                  256-channel tile (measured: no gain per step), 0: always the register-staged conv_wgrad_k.
@@ -440,6 +441,16 @@ int am_match_cost_d(const float* logits, const float* boxes, int D, const int64_
 int am_lsap_batched(const float* cost, int B, int nr, const int32_t* nc_per, int nc_max, long long batch_stride,
                     long long row_stride, long long col_stride, int64_t* row_idx, int64_t* col_idx, int kmax,
                     int32_t* count, int32_t* status, am_stream_t stream);
+/* am_lsap_batched with a caller-owned workspace (am_lsap_batched_workspace_bytes; 0 bytes: the plain form runs): problems whose
+ * short side has at most 32 rows and whose long side at most 1024 (the detection loss, hungarian_matcher.py:76-82: <= 32 boxes
+ * against 920 queries) are solved by the split solver -- per-row sorted candidate lists made on the whole chip, then one wave per
+ * image with the <= 32 assigned columns in registers (lsap.hip) -- and any image in which a tie between candidates could matter,
+ * or which is infeasible, is solved again by the general kernel in the same call, so the results are those of am_lsap_batched
+ * (bit-exact with scipy, ties included).  The workspace is scratch: nothing in it survives the call. */
+int am_lsap_batched_workspace_bytes(int B, int nr, int nc_max, long long* bytes);
+int am_lsap_batched_ws(const float* cost, int B, int nr, const int32_t* nc_per, int nc_max, long long batch_stride,
+                       long long row_stride, long long col_stride, int64_t* row_idx, int64_t* col_idx, int kmax,
+                       int32_t* count, int32_t* status, void* workspace, long long workspace_bytes, am_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step glue on flat fp32 buffers (train_bdd100k_ddp.py:98-99, train_gating_network.py:103-105):

@@ -22,5 +22,11 @@ for (B, Q, N) in [(8, 920, 18), (8, 920, 32), (64, 920, 64), (8, 920, 64)]:
     rows_alike = torch.rand(B, 1, Q, generator=g).expand(B, N, Q) + 1e-4 * torch.rand(B, N, Q, generator=g)
     for name, c in (("random", rnd), ("near-identical columns", same), ("near-identical rows", rows_alike)):
         cd = c.contiguous().to(dev)
-        out.append(f"{name} {t(lambda: hm.lsap_batched(cd, n.to(dev), transposed_storage=True)):8.1f} us")
+        nd = n.to(dev)
+        ts = []
+        for split in (True, False):  # round 3: the split solver (am_lsap_batched_ws) against the general kernels alone
+            hm.USE_SPLIT_SOLVER = split
+            ts.append(t(lambda: hm.lsap_batched(cd, nd, transposed_storage=True)))
+        hm.USE_SPLIT_SOLVER = True
+        out.append(f"{name} split {ts[0]:8.1f} us / general {ts[1]:8.1f} us")
     print(f"B={B} Q={Q} N={N}: " + "   ".join(out), flush=True)

@@ -27,7 +27,7 @@ if os.environ.get("ONLY"):
     layers = [l for l in layers if any(k in l[0] for k in os.environ["ONLY"].split(","))]
 dev = torch.device("cuda:0")
 print(f"B={B} rounds={ROUNDS}")
-names = {0: "ring32", 1: "ring16", 2: "ring16s", 3: "ring16a"}
+names = {0: "ring32", 1: "ring16", 2: "ring16s", 3: "ring16a", 4: "ring16i"}
 tot = {v: 0.0 for v in VARIANTS}
 for name, s, IH, IW in layers:
     x = torch.randn(B, IH, IW, s.cin, device=dev).to(dt)

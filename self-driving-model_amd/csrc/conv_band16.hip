@@ -25,6 +25,21 @@
 // Weights: conv_ring16_k's three 16 KB stages (64-byte rows, XOR swizzle).
 #include "am_common.h"
 
+// Timing ablations for scratch/ablate_band16 (results are garbage with any bit set; the library is built with 0):
+//   1 no LDS-DMA in the K-loop, 2 no s_barrier in the K-loop, 4 no fragment reads in the K-loop, 8 no MFMAs in the K-loop
+#ifndef AMB_ABL
+#define AMB_ABL 0
+#endif
+// AMB_SCHED > 0: the fragment reads and the LDS-DMA pieces of a half K-step are INTERLEAVED with its MFMAs (sched_group_barrier)
+// instead of being issued as a block in front of them: the LDS port is this kernel's second bound (scratch/ablate_band16:
+// MFMA alone 86 us, everything but the MFMAs 65 us, together 134 us on the layer3 shape), and a burst of 8 x 12 wave-reads
+// behind every barrier queues up against the DMA writes.  0: block form (conv_ring16_k's round-2 schedule); 6 (default):
+// first half = four (read, 2 MFMAs) groups, then the DMA pieces one per 2 MFMAs; second half = four (2 reads, 4 MFMAs) groups:
+// 137 -> 112 us on the layer3 shape, 112 -> 105 us on layer4 (B = 32), measured back to back on one box.
+#ifndef AMB_SCHED
+#define AMB_SCHED 6
+#endif
+
 namespace amb {
 
 constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, NTH = NW * 64;
@@ -165,25 +180,81 @@ __global__ __launch_bounds__(NTH) void conv_band16_k(const Params p) {
     const char* P = smem + (c & 1) * patch_bytes;
     const int toff = ky * rowoff + kx * PP;
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments read one half-step ago
+    if constexpr (!(AMB_ABL & 4)) {
 #pragma unroll
-    for (int t = 0; t < HM; ++t) p1[t] = *reinterpret_cast<const half8_t*>(P + pbase[HM + t] + toff);
+      for (int t = 0; t < HM; ++t) p1[t] = *reinterpret_cast<const half8_t*>(P + pbase[HM + t] + toff);
+    }
     // weight tile kk+2 into the stage of tile kk-1 (every wave finished reading it before the last barrier); one piece of the
     // next chunk's patch into the other patch buffer (last read during the previous chunk)
-    if (T_ + 2 < 9) issue_b(T_ + 2, c, istage);
-    else issue_b(T_ + 2 - 9, c + 1, istage);
-    if (T_ < PS) issue_patch(T_, c + 1, (c + 1) & 1);
+    if constexpr (!(AMB_ABL & 1)) {
+      if (T_ + 2 < 9) issue_b(T_ + 2, c, istage);
+      else issue_b(T_ + 2 - 9, c + 1, istage);
+      if (T_ < PS) issue_patch(T_, c + 1, (c + 1) & 1);
+    }
+#if !AMB_SCHED
     __builtin_amdgcn_sched_barrier(0);
+#endif
+    if constexpr (!(AMB_ABL & 8)) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < HM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p0[tm], acc[tn][tm], 0, 0, 0);
+        for (int tm = 0; tm < HM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p0[tm], acc[tn][tm], 0, 0, 0);
+#if AMB_SCHED == 1 || AMB_SCHED == 5
+      // four groups of (one pixel-fragment read, two MFMAs, one LDS-DMA piece if any is left, two MFMAs)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (the LDS-DMA pieces)
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#elif AMB_SCHED == 2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#elif AMB_SCHED == 3 || AMB_SCHED == 6
+      // reads first (one per MFMA), the DMA pieces behind the last MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#elif AMB_SCHED == 4
+      // DMA pieces first (their landing time is the long pole), reads behind
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#endif
+    } else {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) asm volatile("" ::"v"(wc[t]));
+#pragma unroll
+      for (int t = 0; t < HM; ++t) asm volatile("" ::"v"(p0[t]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     // everything older than this K-step's own pieces has landed: weight tile kk+1 and (before a chunk's first tap) its patch
     if (T_ < PS) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BI + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BI) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(AMB_ABL & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
+    if constexpr (!(AMB_ABL & 4)) {
       constexpr int T1 = (T_ + 1) % 9, ky1 = T1 / 3, kx1 = T1 % 3;
       const char* Q = smem + ((T_ + 1 < 9 ? c : c + 1) & 1) * patch_bytes;
       const int toff1 = ky1 * rowoff + kx1 * PP;
@@ -192,15 +263,39 @@ __global__ __launch_bounds__(NTH) void conv_band16_k(const Params p) {
 #pragma unroll
       for (int t = 0; t < HM; ++t) p0[t] = *reinterpret_cast<const half8_t*>(Q + pbase[t] + toff1);
     }
+#if !AMB_SCHED
     __builtin_amdgcn_sched_barrier(0);
+#endif
+    if constexpr (!(AMB_ABL & 8)) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < HM; ++tm) acc[tn][HM + tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p1[tm], acc[tn][HM + tm], 0, 0, 0);
+        for (int tm = 0; tm < HM; ++tm) acc[tn][HM + tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p1[tm], acc[tn][HM + tm], 0, 0, 0);
+#if AMB_SCHED >= 1 && AMB_SCHED <= 4
+      // eight groups of (one read of the next tile's fragments, two MFMAs)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+#elif AMB_SCHED == 5 || AMB_SCHED == 6
+      // the eight reads in pairs
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+#endif
+    } else {
+#pragma unroll
+      for (int t = 0; t < HM; ++t) asm volatile("" ::"v"(p1[t]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     (void)stage;
   };
+#ifndef AMB_NOPRIO
   if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (conv_ring16_k SCHED 1)
+#endif
   using std::integral_constant;
   for (int c = 0; c < nchunk; c += 2) {  // two chunks = 18 K-steps per trip: the weight registers alternate, 9 is odd
     kstep(integral_constant<int, 0>{}, c, wA, wB);

@@ -217,18 +217,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
           for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     } else {
-      // fp32 parity mode: the 16 products of a K-step are summed by the exact-fp32 MFMA chain into a FRESH partial, the partials
-      // into a double master accumulator.  One fp32 chain over the whole contraction (2,304 dependent MFMA steps for a
-      // 512-channel 3x3 layer) left every block output ~1.6x farther from an fp64 run than torch-CPU's vectorised FMA sums
-      // (scratch/dbg_bn_b16.py, round 3) -- and with train-mode BatchNorm + ReLU that noise decides which near-zero
+      // fp32 parity mode: the 16 products of a K-step are summed by the exact-fp32 MFMA chain into a partial,
+      // the partials into a double master accumulator.  One fp32 chain over the whole contraction (2,304 dependent MFMA steps
+      // for a 512-channel 3x3 layer) left every block output ~1.6x farther from an fp64 run than torch-CPU's vectorised FMA
+      // sums (scratch/dbg_bn_b16.py, round 3) -- and with train-mode BatchNorm + ReLU that noise decides which near-zero
       // activations flip, i.e. whether a gradient lands 1e-6 or 5e-3 from the fp64 result.
-      f32x16 part[TM][TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) part[tm][tn][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         float a[TM], b[TN];
@@ -239,14 +232,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_k(const ConvKParams p)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], part[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
+      {  // fold every K-step (every fourth was tried: ~7 % faster in this mode, but the longer fp32 chain showed up as extra ReLU flips in the parity tests)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+          for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dacc[tm][tn][r] += (double)part[tm][tn][r];
+            for (int r = 0; r < 16; ++r) {
+              dacc[tm][tn][r] += (double)acc[tm][tn][r];
+              acc[tm][tn][r] = 0.f;
+            }
+      }
     }
     if (kk + 1 < p.nk) store_tile(stage ^ 1);
     __syncthreads();
@@ -389,6 +387,13 @@ int dispatch_conv(const ConvKParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // 8-wave 256x128 tile: 87 FLOP per byte through the CU's L2->LDS path instead of 64 (the bound of the 128^2 tile)
     if (p.g.N > 64 && p.M >= 256 * 256 && big_tile_mode() == 1) return launch_conv<T, 256, 128, 4, 2>(p, s);
+  }
+  if constexpr (sizeof(T) == 4) {
+    // fp32 parity mode: eight waves per tile -- with the double master accumulators a 4-wave tile needs 192 accumulator registers
+    // per lane (one wave per SIMD: 407 -> 260 img/s for the 4a step in this mode), an 8-wave tile 96
+    if (p.g.N > 64) return launch_conv<T, 128, 128, 4, 2>(p, s);
+    if (p.g.N > 32) return launch_conv<T, 256, 64, 8, 1>(p, s);
+    return launch_conv<T, 256, 32, 4, 1>(p, s);
   }
   if (p.g.N > 64) return launch_conv<T, 128, 128, 2, 2>(p, s);
   if (p.g.N > 32) return launch_conv<T, 256, 64, 4, 1>(p, s);
@@ -549,15 +554,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
           for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     } else {
-      // fp32 parity mode: a fresh fp32 partial per 32-pixel step, summed into a double master (conv_gemm_k's reasoning; the
-      // contraction here runs over every pixel of the chunk)
-      f32x16 part[TMN][TNK];
-#pragma unroll
-      for (int tm = 0; tm < TMN; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TNK; ++tn)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) part[tm][tn][r] = 0.f;
+      // fp32 parity mode: the fp32 chain runs over one 32-pixel step, then folds into a double master (conv_gemm_k's reasoning;
+      // the contraction here runs over every pixel of the chunk)
 #pragma unroll 4
       for (int ks = 0; ks < PS / 2; ++ks) {
         float a[TMN], b[TNK];
@@ -569,14 +567,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const WgradParams p) {
 #pragma unroll
         for (int tm = 0; tm < TMN; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TNK; ++tn) part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], part[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TNK; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
+      {
 #pragma unroll
-      for (int tm = 0; tm < TMN; ++tm)
+        for (int tm = 0; tm < TMN; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TNK; ++tn)
+          for (int tn = 0; tn < TNK; ++tn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dacc[tm][tn][r] += (double)part[tm][tn][r];
+            for (int r = 0; r < 16; ++r) {
+              dacc[tm][tn][r] += (double)acc[tm][tn][r];
+              acc[tm][tn][r] = 0.f;
+            }
+      }
     }
   }
 
@@ -699,7 +702,7 @@ thread_local int g_am_conv_variant = AM_CV_NONE;
 extern "C" int am_conv_last_variant(void) { return g_am_conv_variant; }
 
 static int g_tuning[AM_TUNE_COUNT] = {
-    /* AM_TUNE_RING */ 2,
+    /* AM_TUNE_RING */ 4,
     /* AM_TUNE_RING128_MIN_TILES */ 100,
     /* AM_TUNE_WGRAD_RING */ 1,
     /* AM_TUNE_WGRAD_MAX_SLABS */ 32,

@@ -23,6 +23,10 @@
 // outside the image stay zero (the padding applies to the transformed tensor).
 #include "am_common.h"
 
+#ifndef AMH_SCHED
+#define AMH_SCHED 0  // 1: fragment reads / DMA pieces interleaved with the MFMAs (conv_band16_k gained 15-20 % from it; here +-0 over two A/B runs: 4 MFMAs per half K-step), 0: issued as a block
+#endif
+
 namespace amh {
 
 constexpr int TH = 8, TW = 32;            // output tile
@@ -221,11 +225,23 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
       if (t + 2 < 9) issue_b(t + 2, c, istage);
       else issue_b(t + 2 - 9, c + 1, istage);
       if (t < PSLOTS) issue_patch(t, c + 1, (c + 1) & 1);
+#if !AMH_SCHED
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
+#if AMH_SCHED
+      // reads and LDS-DMA pieces interleaved with the four MFMAs of the half K-step (conv_band16_k's finding: the LDS port is
+      // the second bound, bursts of reads behind the barrier queue up against the DMA writes)
+#pragma unroll
+      for (int i = 0; i < TM * TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        if (i < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read: an LDS-DMA piece
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // everything older than this K-step's own pieces has landed: weight tile kk+1, and (before a chunk's first tap) its patch
       if (t < PSLOTS) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
@@ -240,11 +256,20 @@ __global__ __launch_bounds__(NTH, 4) void conv_halo_k(const HaloParams p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) b0[tn] = *reinterpret_cast<const half8_t*>(smem + fb[0] + nstage * BSTAGE + tn * 32 * BKB);
       }
+#if !AMH_SCHED
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[tm], b1[tn], acc[tm][tn], 0, 0, 0);
+#if AMH_SCHED
+#pragma unroll
+      for (int i = 0; i < TM * TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   }

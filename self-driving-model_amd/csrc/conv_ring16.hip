@@ -14,7 +14,10 @@
 //               segment, static priority for the younger half removes its start-of-segment penalty (MI355X_MICROARCH.md, two
 //               waves per SIMD, item 4): +0.3 % / +3 % / +-0 on the layer3 / layer4 / stride-2 entry shapes;
 //            2  pieces placed by wave age -- waves 0-3 at the END of the segment (under the younger partner's MFMAs, before the
-//               barrier wait), waves 4-7 at its START (right behind the barrier): +-0.
+//               barrier wait), waves 4-7 at its START (right behind the barrier): +-0;
+//            3  (round 3, default) reads and pieces INTERLEAVED with the MFMAs of their half K-step (sched_group_barrier; the
+//               pattern conv_band16_k settled on with its ablation harness): the LDS port -- 96 KB of fragment reads + 32 KB of
+//               DMA writes per 1,024-cycle K-step -- is the second bound, and bursts of reads behind every barrier queue up.
 //     (Dropped: one piece after each of the first MFMA groups: -2 %.)
 // LDS image: rows of 64 bytes (one K-step of one pixel / one output channel), 16-byte chunk c of row r stored at position
 // c ^ swz(r) with swz = {0,2,3,1}[(r >> 2) & 3]: conflict-free for the ds_read_b128 lane groups of the 16x16x32 operand map
@@ -196,12 +199,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
 #pragma unroll
     for (int t = 0; t < HM; ++t) p1[t] = *reinterpret_cast<const half8_t*>(S + fp + (HM + t) * 16 * BKB);
     // tile kk+2 goes where tile kk-1 was: every wave finished reading it before the last barrier
-    if (SCHED == 0 || SCHED == 1) issue_next();
-    __builtin_amdgcn_sched_barrier(0);
+    if (SCHED == 0 || SCHED == 1 || SCHED == 3) issue_next();
+    if (SCHED != 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
       for (int tm = 0; tm < HM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p0[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (SCHED == 3) {
+#pragma unroll
+      for (int i = 0; i < HM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+      }
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read: one LDS-DMA piece
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (SCHED == 2 && !young) issue_next();  // older half: behind its MFMAs, under the younger partner's
@@ -218,15 +233,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_ring16_k(const Params p) {
     for (int t = 0; t < TN; ++t) wnx[t] = *reinterpret_cast<const half8_t*>(Sn + fw + t * 16 * BKB);
 #pragma unroll
     for (int t = 0; t < HM; ++t) p0[t] = *reinterpret_cast<const half8_t*>(Sn + fp + t * 16 * BKB);
-    __builtin_amdgcn_sched_barrier(0);
+    if (SCHED != 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int tm = 0; tm < HM; ++tm) acc[tn][HM + tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[tn], p1[tm], acc[tn][HM + tm], 0, 0, 0);
+    if (SCHED == 3) {
+#pragma unroll
+      for (int i = 0; i < (TN + HM) / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     stage = nstage;
   };
-  if (SCHED == 1 && wid >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if ((SCHED == 1 || SCHED == 3) && wid >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   int kk = 0;
   for (; kk + 1 < nk; kk += 2) {
     kstep(wA, wB);
@@ -440,8 +462,11 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
   const long long mt256 = (p.M + 255) / 256;
   if (g->N >= 256 && mt256 * ((g->N + 255) / 256) >= 200 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K)) {
     if (tile_out) *tile_out = 1;
-    if (am_tuning(AM_TUNE_RING_DIAG)) return launch<256, 256, 2, 4, 1, true>(p, s);  // stamped copy of the default schedule (bench.py's in-kernel clock)
-    return variant == 2 ? launch<256, 256, 2, 4, 2, false>(p, s) : variant == 1 ? launch<256, 256, 2, 4, 1, false>(p, s) : launch<256, 256, 2, 4, 0, false>(p, s);
+    if (am_tuning(AM_TUNE_RING_DIAG)) return launch<256, 256, 2, 4, 3, true>(p, s);  // stamped copy of the default schedule (bench.py's in-kernel clock)
+    return variant == 3   ? launch<256, 256, 2, 4, 3, false>(p, s)
+           : variant == 2 ? launch<256, 256, 2, 4, 2, false>(p, s)
+           : variant == 1 ? launch<256, 256, 2, 4, 1, false>(p, s)
+                          : launch<256, 256, 2, 4, 0, false>(p, s);
   }
   // (the 256x128 tile of this generation lost to conv_ring_k<256,128>: its half K-steps are 8 MFMAs of 16 cycles, too short to
   // cover the fragment reads issued behind the barrier -- 671 vs 784 TFLOP/s on the layer2 shape -- so it is not dispatched)

@@ -13,6 +13,9 @@ def _L():
     return _lib.get()
 
 
+USE_SPLIT_SOLVER = True  # tests flip this to compare the split solver (am_lsap_batched_ws) with the general kernels
+
+
 def lsap_batched(cost: torch.Tensor, n_cols: Optional[torch.Tensor] = None, transposed_storage: bool = False):
     """Solve B assignment problems on the device.
     cost: fp32 [B, nr, nc_max] (or, with transposed_storage, [B, nc_max, nr] holding cost[b, j, i]).
@@ -37,8 +40,18 @@ def lsap_batched(cost: torch.Tensor, n_cols: Optional[torch.Tensor] = None, tran
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     if n_cols is not None:
         n_cols = n_cols.to(device=dev, dtype=torch.int32).contiguous()
-    _L().am_lsap_batched(ptr(cost) if cost.numel() else None, B, nr, ptr(n_cols), nc_max, bs, rs, cs, ptr(rows), ptr(cols), k,
-                         ptr(count), ptr(status), stream())
+    # caller-owned scratch for the split solver (sorted candidate lists + per-image flags): a fresh tensor per call -- a few KB,
+    # and inside a captured step it must live in the graph's pool
+    import ctypes
+    need = ctypes.c_longlong(0)
+    _L().am_lsap_batched_workspace_bytes(B, nr, nc_max, ctypes.byref(need))
+    if need.value > 0 and USE_SPLIT_SOLVER:
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        _L().am_lsap_batched_ws(ptr(cost) if cost.numel() else None, B, nr, ptr(n_cols), nc_max, bs, rs, cs, ptr(rows), ptr(cols), k,
+                                ptr(count), ptr(status), ptr(ws), need.value, stream())
+    else:
+        _L().am_lsap_batched(ptr(cost) if cost.numel() else None, B, nr, ptr(n_cols), nc_max, bs, rs, cs, ptr(rows), ptr(cols), k,
+                             ptr(count), ptr(status), stream())
     return rows, cols, count, status
 
 

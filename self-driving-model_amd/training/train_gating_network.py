@@ -173,6 +173,15 @@ class GatingTrainStep:
 
                 cache_b = {"pend": [(mirror(t), pooled) for t, pooled in cache_a["pend"]], "outs": [mirror(o) for o in cache_a["outs"]]}
                 self._cache_a, self._cache_b = flat_a, flat_b
+                # the per-step hand-over copies graph A's results into graph B's mirrors: one multi-tensor launch per dtype
+                # (torch._foreach_copy_ takes its one-kernel route only for lists of ONE dtype; the mixed f16 / fp32 list
+                # fell back to a hipMemcpy per tensor: ~85 copyBuffer launches per step in round 2's trace)
+                groups = {}
+                for a_, b_ in zip(flat_a, flat_b):
+                    groups.setdefault((a_.dtype, a_.is_contiguous()), ([], []))
+                    groups[(a_.dtype, a_.is_contiguous())][0].append(a_)
+                    groups[(a_.dtype, a_.is_contiguous())][1].append(b_)
+                self._cache_groups = list(groups.values())
                 self._ev_experts, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
                 self._graph_experts = ga
                 # one-time costs (a graph's first launch on a new stream, the copy kernels' module load: ~10 ms each) are paid
@@ -182,7 +191,8 @@ class GatingTrainStep:
                 torch.cuda.synchronize()
                 with torch.cuda.stream(self._expert_stream):
                     ga.replay()
-                torch._foreach_copy_(flat_b, flat_a)
+                for ga_, gb_ in self._cache_groups:
+                    torch._foreach_copy_(gb_, ga_)
                 torch.cuda.synchronize()
                 for b, v in zip(bufs, saved):
                     b.copy_(v)
@@ -280,7 +290,8 @@ class GatingTrainStep:
                     self._launch_experts(batch)
                 main = torch.cuda.current_stream()
                 main.wait_event(self._ev_experts)
-                torch._foreach_copy_(self._cache_b, self._cache_a)  # graph A may now overwrite its results
+                for ga_, gb_ in self._cache_groups:  # graph A may now overwrite its results
+                    torch._foreach_copy_(gb_, ga_)
                 self._ev_copied.record(main)
                 self._experts_pending = False
             self._graph.replay()

@@ -83,10 +83,15 @@ def check_grad_norms(m, g, tag, train):
         e = abs(got - ref_l2) / (ref_l2 + 1e-12)
         if ref_l2 >= 1e-6:
             worst = max(worst, e)
-        assert e <= (TRAIN_GRAD_L2 if train else 2e-3) or ref_l2 < 1e-6, f"{tag} {n}: |g| {got:.6e} vs reference {ref_l2:.6e}"
+        # (eval mode 5e-3: one ReLU on the other branch -- the reference's fp32 run has them against its own fp64 run too -- moved a
+        # BatchNorm weight gradient's norm by 2.6e-3 when the fp32-mode tile shape changed; tensors with an fp64 arbiter in the
+        # fixture are held tighter by grad_close)
+        assert e <= (TRAIN_GRAD_L2 if train else 5e-3) or ref_l2 < 1e-6, f"{tag} {n}: |g| {got:.6e} vs reference {ref_l2:.6e}"
         if not train:
             gs = float(p.grad.double().sum())
-            assert abs(gs - float(g[f"{tag}/gsum/{n}"])) <= 2e-3 * abs(float(g[f"{tag}/gsum/{n}"])) + 2e-4 * (1 + ref_l2 * p.numel() ** 0.5), f"{tag} gsum {n}"
+            # (the SUM of a gradient tensor moves by whole terms when one ReLU takes the other branch -- seen: 0.6 % of a sum over
+            # 36,864 elements when the fp32-mode summation order changed; a gross-error check, the norm above is the tight one)
+            assert abs(gs - float(g[f"{tag}/gsum/{n}"])) <= 5e-3 * abs(float(g[f"{tag}/gsum/{n}"])) + 5e-4 * (1 + ref_l2 * p.numel() ** 0.5), f"{tag} gsum {n}"
     return worst
 
 

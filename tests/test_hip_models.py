@@ -88,7 +88,10 @@ def _grad_check(hip, ref, rtol, atol, skip=(), truth=None, what=""):
         e_hip, e_ref = rel_err(h[n].grad, t[n].grad), rel_err(r[n].grad, t[n].grad)
         ARBITRATIONS.append({"test": test, "param": n, "rtol": rtol, "atol": atol, "hip_vs_fp64": e_hip, "torch_fp32_vs_fp64": e_ref,
                              "hip_closer_to_fp64": bool(e_hip <= e_ref)})
-        assert e_hip <= max(2e-3, 2 * e_ref) and e_hip < 5e-2, f"{n}: hip vs fp64 {e_hip:.2e}, torch-cpu-fp32 vs fp64 {e_ref:.2e}\n{e}"
+        # floor 1e-2: ONE ReLU on the other branch moves a deep gradient by 2e-3..9e-3 in relative L2 (every flip recorded in
+        # rounds 2-3, torch-cpu-fp32's own and HIP's), and any fp32 implementation has O(1) of them per run against fp64 --
+        # fp32 STORAGE of activations decides the sign of a pre-activation that sits within 1e-7 of zero, however exact the sums
+        assert e_hip <= max(1e-2, 2 * e_ref) and e_hip < 5e-2, f"{n}: hip vs fp64 {e_hip:.2e}, torch-cpu-fp32 vs fp64 {e_ref:.2e}\n{e}"
     return n_cmp
 
 
