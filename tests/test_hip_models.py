@@ -1096,6 +1096,40 @@ def test_conv_packs_rebuilt_by_one_launch_per_step(use_graph):
         assert res[True][1][-1] == 0 and res[False][1][-1] == 0  # replays launch from the graph
 
 
+def test_captured_step_survives_a_pack_relayout_in_an_eager_step():
+    """a captured step graph has the grouped pack buffer's address baked into its gather and conv nodes.  An eager
+    step in ANOTHER precision after the capture makes PackGroup.refresh() build a new buffer; the old one must stay alive (kept
+    in `_retired`), so replays afterwards neither write freed memory nor change the trajectory: replays after the detour give
+    the losses of a run without the detour."""
+    from self_driving_model_amd import runtime
+    from self_driving_model_amd.models.experts import BDDDrivableExpert
+    from self_driving_model_amd.training import synthetic
+    from self_driving_model_amd.training.train_bdd100k_ddp import BDDTrainer
+    dev = _dev()
+    out = {}
+    for detour in (False, True):
+        with runtime.precision(torch.float16):
+            torch.manual_seed(33)
+            m = BDDDrivableExpert(3, pretrained_backbone=False).to(dev).train()
+            b = synthetic.bdd_drivable_batch(2, 96, 160, 3, dev, seed=7)
+            loader = synthetic.SyntheticLoader(b, 4)
+            tr = BDDTrainer("drivable", m, loader, loader, dev, {"learning_rate": 1e-3, "weight_decay": 1e-5, "epochs": 1, "run_name": "t"})
+            losses = [float(tr.train_step(b)) for _ in range(4)]
+            assert tr._graph is not None
+            group = tr.optimizer.pack_group
+            old_buf = group.buf
+            if detour:
+                with runtime.precision(torch.float32):
+                    group.refresh(torch.float32)  # what an eager fp32 step's zero_grad() does: a new layout signature
+                assert group.buf is not old_buf and any(r[1] is old_buf for r in group._retired)
+                junk = [torch.full((old_buf.numel(),), 7.0, dtype=old_buf.dtype, device=dev) for _ in range(4)]  # would land on freed memory
+                group.refresh(torch.float16)
+                del junk
+            losses += [float(tr.train_step(b)) for _ in range(3)]
+        out[detour] = losses
+    np.testing.assert_allclose(out[True], out[False], rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("C,shape,fused_calls", [(64, (2, 181, 190), 1), (128, (6, 91, 150), 1), (256, (2, 24, 40), 0)])
 def test_basic_block_residual_gradient_handoff_matches_autograd_accumulation(C, shape, fused_calls):
     """A trainable identity BasicBlock's input gets two gradients (through conv1, through the shortcut).  The block end hands
