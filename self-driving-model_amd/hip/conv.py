@@ -943,10 +943,11 @@ def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, 
     raw1 = torch.empty_like(x)
     stats1 = _runtime().arena_zeros(AM_STATS_REPLICAS * 2 * C, dev)
     w1 = cache1.get_fwd(conv1_w, s, x.dtype)
+    nbytes = 2.0 * (2 * P * C + 9 * C * C)  # algorithmic: input + output once each, weights
     if pre is not None:
         try:
             _timed("conv_gemm", flops, lambda: L.am_conv_gemm_prebn(ctypes.byref(g), AM_F16, ptr(x), ptr(pre[0]), ptr(pre[1]), ptr(w1), ptr(raw1),
-                                                                  ptr(stats1), stream()))
+                                                                  ptr(stats1), stream()), nbytes)
         except RuntimeError as e:
             if "UNSUPPORTED" not in str(e):
                 raise
@@ -959,7 +960,7 @@ def fused_basic_block_identity(x, conv1_w, bn1, cache1: PackedWeights, conv2_w, 
     w2 = cache2.get_fwd(conv2_w, s, x.dtype)
     try:
         _timed("conv_gemm", flops, lambda: L.am_conv_gemm_prebn(ctypes.byref(g), AM_F16, ptr(raw1), ptr(sc1), ptr(sh1), ptr(w2), ptr(raw2),
-                                                              ptr(stats2), stream()))
+                                                              ptr(stats2), stream()), nbytes)
     except RuntimeError as e:
         if "UNSUPPORTED" not in str(e):
             raise
@@ -1033,7 +1034,7 @@ def fused_basic_block_down(x, blk):
         try:
             _timed("conv_gemm", 2.0 * P * s2.cin * 9 * C, lambda: L.am_conv_gemm_prebn(
                 ctypes.byref(g2), AM_F16, ptr(raw1), ptr(sc1), ptr(sh1), ptr(blk.conv2._packed.get_fwd(blk.conv2.weight, s2, x.dtype)),
-                ptr(raw2), ptr(st2), stream()))
+                ptr(raw2), ptr(st2), stream()), 2.0 * (2 * P * C + 9 * C * C))
         except RuntimeError as e:
             if "UNSUPPORTED" not in str(e):
                 raise
