@@ -18,6 +18,15 @@
 #include "am_common.h"
 #include <cstdlib>
 
+// Timing ablations for scratch/ablate_duo (garbage results with any bit set; the library is built with 0):
+//   1 no patch LDS-DMA in the tile loop, 2 no MFMAs, 4 no fragment reads, 8 no global stores
+#ifndef AMP3_ABL
+#define AMP3_ABL 0
+#endif
+#ifndef AMP3_VMCNT4
+#define AMP3_VMCNT4 1  // 1 (round 3): the previous tile's four stores stay in flight across the patch wait (vmcnt(4)): 148 -> 142 us at B = 32
+#endif
+
 namespace amp3 {
 
 constexpr int TH = 8, TW = 16;             // output tile of one group
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
       for (int s = 0; s < 18 + 1; ++s) {
         if (s >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): step s-1's fragments
         __builtin_amdgcn_sched_barrier(0);
-        if (s < 18) {
+        if (s < 18 && !(AMP3_ABL & 4)) {
           const int tap = s >> 1, ks2 = s & 1, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
           for (int pb = 0; pb < 4; ++pb)
@@ -274,11 +283,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
         if (s >= 1) {
           const int c = (s - 1) & 1;
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (!(AMP3_ABL & 2)) {
 #pragma unroll
-          for (int pb = 0; pb < 4; ++pb)
+            for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
-            for (int ca = 0; ca < 2; ++ca)
-              acc4[pb][ca] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(s - 1) * 2 + ca], fq[c][pb], s == 1 ? z : acc4[pb][ca], 0, 0, 0);
+              for (int ca = 0; ca < 2; ++ca)
+                acc4[pb][ca] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(s - 1) * 2 + ca], fq[c][pb], s == 1 ? z : acc4[pb][ca], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+              asm volatile("" ::"v"(fq[c][pb]));
+              if (s == 1) { acc4[pb][0] = z; acc4[pb][1] = z; }
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -314,14 +331,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     // done; after the barrier the next patch is complete and nobody reads the current one any more -- so the patch after
     // next goes into the buffer just read, two tiles ahead of its use (an LDS-DMA from HBM takes longer than one MFMA
     // phase under load).  Raw barrier + asm wait: __syncthreads() would do, the explicit form documents what is ordered.
+#if AMP3_VMCNT4
+    // the four stores of the previous tile's epilogue are the wave's youngest vector-memory operations: leave them in flight
+    // (the next patch's pieces, issued before them, have landed once only four remain outstanding)
+    if (EPI && has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the residual loads of this tile are younger still)
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (pre && tile + per_xcd < tend) {
       transform_patch(tile + per_xcd, buf ^ 1);  // this wave's share of the next patch has landed: rewrite it in place
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (tile + 2 * per_xcd < tend) issue_patch(tile + 2 * per_xcd, buf);
+    if (!(AMP3_ABL & 1) && tile + 2 * per_xcd < tend) issue_patch(tile + 2 * per_xcd, buf);
     buf ^= 1;
 
     // ------------------------------- epilogue -------------------------------
@@ -408,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (int)am_addh2_act((unsigned)v[e], (unsigned)resv[it][e], relu_late);
       }
-      buffer_store16_asm(v, yr, vo);
+      if constexpr (!(AMP3_ABL & 8)) buffer_store16_asm(v, yr, vo);
+      else asm volatile("" ::"v"(v), "v"(vo));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the next tile's writes
   }
