@@ -129,7 +129,7 @@ int am_conv_gemm_res(const am_conv_geom* g, int dtype, const void* x, const void
  * 0 none, 1 conv_ring_k<256,256>, 2 conv_ring_k<256,128>, 3 conv3x3_c64n64_duo_k, 4 (retired), 5 (retired),
  * 6 conv_gemm2_k, 7 (retired), 8 conv_gemm_k (register-staged), 9 conv_s2d_k, 10 conv_s2d_pool_k,
  * 11 conv_ring16_k<256,256>, 12 conv_ring16_k<256,128>, 13 wgrad_ring_k, 14 conv_wgrad_k (register-staged), 15 conv_s2d_wgrad_k,
- * 16 conv_halo_k, 17 conv_patch_wgrad_k, 18 conv_band16_k. */
+ * 16 conv_halo_k, 17 conv_patch_wgrad_k, 18 conv_band16_k, 19 conv_ring16_k<128,256>. */
 int am_conv_last_variant(void);
 
 /* Process-wide A/B switches between kernels that compute the same result (diagnostic / tuning use: tests pin a kernel, bench
@@ -156,7 +156,10 @@ int am_conv_last_variant(void);
  *   AM_TUNE_BAND_MIN_TILES 3x3 / stride-1 layers with N a multiple of 256 take the row-band halo kernel (conv_band16_k) from this
  *                          many 256x256 tiles on (default 200: conv_ring16_k's gate; a huge value sends them to the ring kernels).
  *   AM_TUNE_RING_DIAG      1: conv_ring16_k launches its diagnostic instantiation (workgroup 0 stamps the K-loop's cycle / wall
- *                          counters for am_diag_ring_clock); 0 (default): the production kernel carries no stamp. */
+ *                          counters for am_diag_ring_clock); 0 (default): the production kernel carries no stamp.
+ *   AM_TUNE_RING16_M128_MIN_TILES problems with N >= 256 that make fewer than 200 tiles of 256x256 (layer 4 at B <= 16, the 512 -> 256
+ *                          heads) take conv_ring16_k's 128x256 tile from this many 128x256 tiles on (default 200: +3-6 % over conv_ring_k<256,128>
+ *                          there, slower below; a huge value: never). */
 #define AM_TUNE_RING 0
 #define AM_TUNE_RING128_MIN_TILES 1
 #define AM_TUNE_WGRAD_RING 2
@@ -168,7 +171,8 @@ int am_conv_last_variant(void);
 #define AM_TUNE_DUO_MFMA16 8
 #define AM_TUNE_BAND_MIN_TILES 9
 #define AM_TUNE_RING_DIAG 10
-#define AM_TUNE_COUNT 11
+#define AM_TUNE_RING16_M128_MIN_TILES 11
+#define AM_TUNE_COUNT 12
 int am_set_tuning(int key, int value);
 int am_get_tuning(int key);
 

@@ -97,7 +97,8 @@ static inline int am_current_device() {
 enum am_conv_variant_id {
   AM_CV_NONE = 0, AM_CV_RING_256x256, AM_CV_RING_256x128, AM_CV_DUO_C64, AM_CV_WREG_C64, AM_CV_PATCH_C64, AM_CV_LDSDMA_V2,
   AM_CV_LDSDMA_RING_V1, AM_CV_REGSTAGED, AM_CV_S2D, AM_CV_S2D_POOL, AM_CV_RING16_256x256, AM_CV_RING16_256x128,
-  AM_CV_WGRAD_RING, AM_CV_WGRAD_REGSTAGED, AM_CV_WGRAD_S2D, AM_CV_HALO_256x128, AM_CV_WGRAD_PATCH_C64, AM_CV_BAND16_256x256
+  AM_CV_WGRAD_RING, AM_CV_WGRAD_REGSTAGED, AM_CV_WGRAD_S2D, AM_CV_HALO_256x128, AM_CV_WGRAD_PATCH_C64, AM_CV_BAND16_256x256,
+  AM_CV_RING16_128x256
 };
 extern thread_local int g_am_conv_variant;
 

@@ -713,6 +713,7 @@ static int g_tuning[AM_TUNE_COUNT] = {
     /* AM_TUNE_DUO_MFMA16 */ 1,
     /* AM_TUNE_BAND_MIN_TILES */ 200,
     /* AM_TUNE_RING_DIAG */ 0,
+    /* AM_TUNE_RING16_M128_MIN_TILES */ 200,
 };
 
 int am_tuning(int key) { return key >= 0 && key < AM_TUNE_COUNT ? g_tuning[key] : 0; }

@@ -387,7 +387,7 @@ int am_conv_ring_f16(const am_conv_geom* g, const void* x, const void* w, const 
   if (const int t = am_tuning(AM_TUNE_RING); t > 0) {  // 16x16x32 generation (conv_ring16.hip): the 256x256 tile
     int tile = 0;
     const int rc = am_conv_ring16_f16(g, x, w, bias, relu, res, y, stats, t - 1, &tile, s);
-    if (rc == AM_OK) g_am_conv_variant = tile == 1 ? AM_CV_RING16_256x256 : AM_CV_RING16_256x128;
+    if (rc == AM_OK) g_am_conv_variant = tile == 1 ? AM_CV_RING16_256x256 : tile == 3 ? AM_CV_RING16_128x256 : AM_CV_RING16_256x128;
     if (rc != AM_ERR_UNSUPPORTED) return rc;
   }
   if (g->ntaps <= 0 || g->ntaps > RING_MAX_TAPS || g->pix_shift != 31 || (g->krun * 2) % 64 != 0 || g->N <= 64) return AM_ERR_UNSUPPORTED;

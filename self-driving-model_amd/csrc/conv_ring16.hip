@@ -430,7 +430,7 @@ int launch(const Params& p0, hipStream_t s) {
 }  // namespace amr16
 
 // variant = SCHED of conv_ring16_k (0 block, 1 spread, 2 by wave age).
-// Returns AM_ERR_UNSUPPORTED when the shape is not covered; *tile_out: 1 = 256x256, 2 = 256x128.
+// Returns AM_ERR_UNSUPPORTED when the shape is not covered; *tile_out: 1 = 256x256, 2 = 256x128, 3 = 128x256.
 int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, const float* bias, int relu, const void* res, void* y,
                        double* stats, int variant, int* tile_out, hipStream_t s) {
   using namespace amr16;
@@ -467,6 +467,12 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
            : variant == 2 ? launch<256, 256, 2, 4, 2, false>(p, s)
            : variant == 1 ? launch<256, 256, 2, 4, 1, false>(p, s)
                           : launch<256, 256, 2, 4, 0, false>(p, s);
+  }
+  // 58-199 tiles of 256x256 (layer 4 at B <= 16, the 512 -> 256 heads): half of the chip's CUs would idle; a 128-row tile doubles the
+  // workgroup count (wave tile 64 x 64: 0.5 fragment reads per MFMA instead of 0.375, so a slower tile -- but twice as many CUs work)
+  if (g->N >= 256 && p.nk > am_tuning(AM_TUNE_RING_SHORT_K) && ((p.M + 127) / 128) * ((g->N + 255) / 256) >= am_tuning(AM_TUNE_RING16_M128_MIN_TILES)) {
+    if (tile_out) *tile_out = 3;
+    return launch<128, 256, 2, 4, 3, false>(p, s);
   }
   // (the 256x128 tile of this generation lost to conv_ring_k<256,128>: its half K-steps are 8 MFMAs of 16 cycles, too short to
   // cover the fragment reads issued behind the barrier -- 671 vs 784 TFLOP/s on the layer2 shape -- so it is not dispatched)

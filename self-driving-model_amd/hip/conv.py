@@ -394,7 +394,7 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 CONV_KERNEL_NAMES = {1: "conv_ring_k<256,256,2,4>", 2: "conv_ring_k<256,128,4,2>", 3: "conv3x3_c64n64_duo_k", 6: "conv_gemm2_k", 8: "conv_gemm_k",
                      9: "conv_s2d_k", 10: "conv_s2d_pool_k", 11: "conv_ring16_k<256,256,2,4>", 12: "conv_ring16_k<256,128,4,2>",
-                     16: "conv_halo_k", 18: "conv_band16_k"}
+                     16: "conv_halo_k", 18: "conv_band16_k", 19: "conv_ring16_k<128,256,2,4>"}
 
 
 def _timed(kind: str, flops: float, fn, nbytes: float = 0.0):

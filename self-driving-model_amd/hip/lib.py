@@ -31,6 +31,7 @@ AM_TUNE_PATCH_WGRAD_C128 = 7
 AM_TUNE_DUO_MFMA16 = 8
 AM_TUNE_BAND_MIN_TILES = 9
 AM_TUNE_RING_DIAG = 10
+AM_TUNE_RING16_M128_MIN_TILES = 11
 
 _ERR = {-1: "AM_ERR_ARG (bad argument)", -2: "AM_ERR_LAUNCH (HIP runtime refused the launch)",
         -3: "AM_ERR_UNSUPPORTED (shape/dtype not built)"}
@@ -123,7 +124,8 @@ class _Lib:
         for key, idx in (("RING", AM_TUNE_RING), ("RING128_MIN_TILES", AM_TUNE_RING128_MIN_TILES), ("WGRAD_RING", AM_TUNE_WGRAD_RING), ("WGRAD_MAX_SLABS", AM_TUNE_WGRAD_MAX_SLABS),
                          ("RING_SHORT_K", AM_TUNE_RING_SHORT_K), ("HALO_MIN_TILES", AM_TUNE_HALO_MIN_TILES),
                          ("PATCH_WGRAD_MIN_TILES", AM_TUNE_PATCH_WGRAD_MIN_TILES), ("PATCH_WGRAD_C128", AM_TUNE_PATCH_WGRAD_C128),
-                         ("DUO_MFMA16", AM_TUNE_DUO_MFMA16), ("BAND_MIN_TILES", AM_TUNE_BAND_MIN_TILES), ("RING_DIAG", AM_TUNE_RING_DIAG)):
+                         ("DUO_MFMA16", AM_TUNE_DUO_MFMA16), ("BAND_MIN_TILES", AM_TUNE_BAND_MIN_TILES), ("RING_DIAG", AM_TUNE_RING_DIAG),
+                         ("RING16_M128_MIN_TILES", AM_TUNE_RING16_M128_MIN_TILES)):
             v = os.environ.get("AUTOMOE_TUNE_" + key)
             if v is not None:
                 self.am_set_tuning(idx, int(v))

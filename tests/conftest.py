@@ -48,7 +48,7 @@ def _oracle_built():
 KERNELS = {0: "none", 1: "conv_ring_k<256,256>", 2: "conv_ring_k<256,128>", 3: "conv3x3_c64n64_duo_k", 4: "(retired)",
            5: "(retired)", 6: "conv_gemm2_k", 7: "(retired)", 8: "conv_gemm_k", 9: "conv_s2d_k", 10: "conv_s2d_pool_k",
            11: "conv_ring16_k<256,256>", 12: "conv_ring16_k<256,128>", 13: "wgrad_ring_k", 14: "conv_wgrad_k", 15: "conv_s2d_wgrad_k", 16: "conv_halo_k",
-           17: "conv_patch_wgrad_k", 18: "conv_band16_k"}
+           17: "conv_patch_wgrad_k", 18: "conv_band16_k", 19: "conv_ring16_k<128,256>"}
 
 
 def launched_kernel(expect=None, what=""):

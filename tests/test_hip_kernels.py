@@ -708,6 +708,49 @@ def test_conv_big_tile_variant_vs_torch(case):
     np.testing.assert_allclose(st_[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
 
 
+@pytest.mark.parametrize("case", [(512, 512, 3, 1, 1, 16, 23, 40), (512, 256, 3, 1, 1, 32, 23, 40), (256, 512, 3, 2, 1, 16, 45, 80)])
+def test_conv_ring16_m128_tile_vs_torch_and_the_tile_it_replaces(case):
+    """Problems with N >= 256 that make 58-199 tiles of 256x256 (ResNet layer 4 at B = 16, the 512 -> 256 heads at B = 32): half the
+    CUs would idle, so conv_ring16_k runs them on its 128x256 tile (AM_TUNE_RING16_M128_MIN_TILES).  Forward, bias + ReLU epilogue and
+    BatchNorm statistics against torch on the f16-rounded operands and against conv_ring_k<256,128>, which took them before."""
+    from self_driving_model_amd.hip import conv as hc, lib
+    cin, cout, k, st, pad, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout + B)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).half().float()
+    bias = torch.randn(cout, generator=g)
+    yr = F.conv2d(x, w, stride=st, padding=pad)
+    s = hc.ConvSpec(cin, cout, k, st, pad)
+    OH, OW = yr.shape[2], yr.shape[3]
+    m128 = -(-B * OH * OW // 128) * -(-cout // 256)
+    assert -(-B * OH * OW // 256) * -(-cout // 256) < 200 <= m128
+    geom, xd, wp = hc.fwd_geom(s, B, H, W, cin, cout, 2), nhwc(x, torch.float16), hc.pack_fwd(w.to(_dev()), s, torch.float16)
+    L = lib.get()
+    outs = {}
+    old = L.am_get_tuning(lib.AM_TUNE_RING16_M128_MIN_TILES)
+    try:
+        for gate, name in ((200, "conv_ring16_k<128,256>"), (1 << 30, "conv_ring_k<256,128>")):
+            L.am_set_tuning(lib.AM_TUNE_RING16_M128_MIN_TILES, gate)
+            y = torch.zeros(B, OH, OW, cout, dtype=torch.float16, device=_dev())
+            stats = torch.zeros(16 * 2 * cout, dtype=torch.float64, device=_dev())
+            hc.conv_gemm(geom, xd, wp, None, False, y, stats)
+            launched_kernel(name, what=f"m128 tile {case} gate={gate}")
+            yb = torch.zeros_like(y)
+            hc.conv_gemm(geom, xd, wp, bias.to(_dev()), True, yb, None)
+            launched_kernel(name, what=f"m128 tile {case} gate={gate} bias+relu")
+            torch.cuda.synchronize()
+            outs[gate] = (y.float().cpu(), stats.view(16, 2, cout).sum(0).cpu(), yb.float().cpu())
+    finally:
+        L.am_set_tuning(lib.AM_TUNE_RING16_M128_MIN_TILES, old)
+    y, st_, yb = outs[200]
+    close(nchw(y, cout), yr, rtol=3e-3, atol=3e-3)
+    close(nchw(yb, cout), torch.relu(yr + bias.view(1, -1, 1, 1)), rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(st_[0].numpy(), yr.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=1.0)
+    np.testing.assert_allclose(st_[1].numpy(), (yr.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-3)
+    assert rel_err(y, outs[1 << 30][0]) < 1e-3  # (f16 roundings of two fp32 summation orders)
+    np.testing.assert_allclose(st_.numpy(), outs[1 << 30][1].numpy(), rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("norm", [False, True])
 def test_uint8_frames_boundary_matches_reference_preprocessing(norm):
     """uint8 frames -> /255 (-> ImageNet normalise) -> space-to-depth NHWC in one kernel,
