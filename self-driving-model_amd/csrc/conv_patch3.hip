@@ -11,7 +11,9 @@
 //     phase, so while one runs MFMAs the other runs its epilogue / issues its next patch DMA on the same SIMDs;
 //   * input patch: 10 x 18 pixels at a 144-byte LDS pitch (conflict-free ds_read_b128 without a swizzle, every
 //     (tap, k16-step) offset an instruction immediate), filled by buffer_load ... lds (out-of-range offsets give the
-//     zero padding);
+//     zero padding); in the 16x16x32 form (160-byte pitch) one LDS-DMA wave-instruction delivers six whole pixels, so its
+//     patch row / column base are wave-uniform and a lane's chunk is fixed: ~4 instead of ~28 VALU instructions per piece,
+//     and the input transform reads its scale / shift once per tile;
 //   * MFMAs run "transposed" (A = weights, B = pixels): a lane owns one pixel and four consecutive channels per register
 //     quad -- packed adds / FMAs for the BN statistics, v_cvt_pk_f16_f32, 8-byte LDS staging writes, 16-byte stores;
 //   * stores are inline-asm buffer stores (see buffer_store16_asm) so that the patch prefetch stays in flight across them.
@@ -22,6 +24,9 @@
 //   1 no patch LDS-DMA in the tile loop, 2 no MFMAs, 4 no fragment reads, 8 no global stores
 #ifndef AMP3_ABL
 #define AMP3_ABL 0
+#endif
+#ifndef AMP3_FRING
+#define AMP3_FRING 7  // M16 form: prefetch distance of the fragment ring in fragments (0: the step-wise form, four fragments per eight MFMAs)
 #endif
 #ifndef AMP3_VMCNT4
 #define AMP3_VMCNT4 1  // 1 (round 3): the previous tile's four stores stay in flight across the patch wait (vmcnt(4)): 148 -> 142 us at B = 32
@@ -47,6 +52,12 @@ struct Lay {
   static constexpr int NINST = (NPIX * CPP + 63) / 64;     // wave-instructions of 64 x 16 B (26 / 29)
   static constexpr int PATCH_SLOT = NINST * 1024;
   static constexpr int IPW = (NINST + 3) / 4;              // instructions per wave of a group (the last ones are skipped)
+  // M16 (round 3): a DMA wave-instruction delivers 6 whole patch pixels (60 chunks = 960 B; lanes 60-63 and the two pad chunks of a
+  // pixel are masked off) -- 18 = 3 x 6, so piece n is patch row n / 3, columns (n % 3) * 6 + lane / 10: row, column base and LDS
+  // address are wave-uniform, a lane's chunk (lane % 10) and byte offset inside the piece never change
+  static constexpr int PIECE_PIX = 6, NPIECE = NPIX / PIECE_PIX, PIECE_BYTES = PIECE_PIX * PP;
+  static_assert(4 * IPW - 2 == NPIECE || !M16, "the last wave has two pieces less");
+  static_assert(!M16 || (NPIX % PIECE_PIX == 0 && PW % PIECE_PIX == 0 && PIECE_PIX * CPP <= 64 && (NPIECE + 3) / 4 == IPW && NPIECE * PIECE_BYTES <= PATCH_SLOT), "pieces");
   static constexpr int PATCH_BYTES = 2 * PATCH_SLOT;       // double buffer
   static constexpr int LDS_BYTES = PATCH_BYTES + 4 * STG_WAVE + 1024;  // 74,752 / 80,896: two workgroups per CU
   static_assert(64 * WROW <= PATCH_BYTES + 4 * STG_WAVE, "weights pass through the patch + staging area once");
@@ -144,8 +155,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   char* const gpatch = smem;
   float* const aff = reinterpret_cast<float*>(smem + PATCH_BYTES + 4 * STG_WAVE);  // [2][64] scale, shift (input transform)
-  const bool pre = p.pre_scale != nullptr;
+  const bool pre = !EPI && p.pre_scale != nullptr;  // (the host entry refuses an input transform together with the inference epilogue)
   if (pre && tid < 128) aff[tid] = tid < 64 ? p.pre_scale[tid] : p.pre_shift[tid - 64];
+
+  // M16: a lane's fixed place inside every DMA piece -- pixel pl, chunk pcc -- recomputed per call from an opaque copy of the lane id
+  // (a handful of instructions; kept across the tile loop they cost registers the kernel does not have)
+#define AMP3_LANE_PLACE()                                                  \
+  int ln = lane;                                                           \
+  asm volatile("" : "+v"(ln));                                             \
+  const int pl = ln / 10, pcc = ln - pl * 10;                              \
+  const bool dma_lane = ln < L::PIECE_PIX * 10 && pcc < 8;
 
   auto issue_patch = [&](int tile, int buf) {
     const int img = tile / tiles_per_img;
@@ -153,6 +172,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
     const unsigned tb = (unsigned)((((img * p.H + iy0) * p.W + ix0) * p.ldi + p.x_coff) * 2);  // wraps for the halo row/col: fine
+    if constexpr (M16) {
+      char* dst = gpatch + buf * PATCH_SLOT;
+      AMP3_LANE_PLACE();
+      const unsigned lane_off = (unsigned)(pl * pix_bytes + pcc * 16);
+      if (dma_lane) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+          const int n = w4 * IPW + i;
+          if (n < L::NPIECE) {
+            const int prow = n / 3, pc0 = (n - prow * 3) * L::PIECE_PIX;  // wave-uniform
+            const bool ok = (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pc0 + pl) < (unsigned)p.W;
+            const unsigned vo = ok ? tb + (unsigned)(prow * row_bytes + pc0 * pix_bytes) + lane_off : OOB;  // outside the image: zeros
+            buffer_to_lds16(p.x, p.x_bytes, dst + n * L::PIECE_BYTES, vo);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
     char* dst = gpatch + buf * PATCH_SLOT + w4 * (IPW * 1024);
     // LDS position q = (w4*IPW + i)*64 + lane -> patch pixel q/CPP, 16-byte chunk q%CPP (chunks >= 8 = pad).  Recomputed per tile
     // from an opaque copy of the lane id: values hipcc hoists out of the tile loop end up spilled, and a spill reload
@@ -181,6 +219,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+    if constexpr (M16) {
+      AMP3_LANE_PLACE();
+      char* dst = gpatch + buf * PATCH_SLOT + ln * 16;
+      if (dma_lane) {
+        // the lane's eight channels never change: one read of their scale / shift per tile
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + pcc * 8), s1 = *reinterpret_cast<const f32x4*>(aff + pcc * 8 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + 64 + pcc * 8), h1 = *reinterpret_cast<const f32x4*>(aff + 64 + pcc * 8 + 4);
+        // Straight-line code (no per-chunk branch: the scheduler interleaves the eight independent chunks, no dependent packed op
+        // waits on its predecessor): all of the lane's chunks are requested first (one LDS round trip per tile; out-of-image chunks
+        // hold the DMA's zeros and are read for nothing), transformed, and written back -- an out-of-image chunk's result goes to the
+        // unused pad chunk of its pixel instead (the padding must stay zero).
+        auto piece = [&](auto first, auto last) {
+          constexpr int I0 = decltype(first)::value, I1 = decltype(last)::value;
+          half8_t vin[I1 - I0];
+#pragma unroll
+          for (int i = I0; i < I1; ++i) vin[i - I0] = *reinterpret_cast<const half8_t*>(dst + (w4 * IPW + i) * L::PIECE_BYTES);
+#pragma unroll
+          for (int i = I0; i < I1; ++i) {
+            const int n = w4 * IPW + i;
+            const int prow = n / 3, pc0 = (n - prow * 3) * L::PIECE_PIX;
+            const bool ok = (unsigned)(iy0 + prow) < (unsigned)p.H && (unsigned)(ix0 + pc0 + pl) < (unsigned)p.W;
+            // two channels per instruction: packed fp32 multiply, packed fp32 add (unfused, bn_apply_k's arithmetic), one packed
+            // f16 conversion, packed f16 max -- max(round(t), 0) = round(max(t, 0)): rounding is monotone and keeps zero
+            const half8_t v = vin[i - I0];
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 xv = {(float)v[2 * e], (float)v[2 * e + 1]};
+              const f32x2 sc2 = e < 2 ? f32x2{s0[2 * e], s0[2 * e + 1]} : f32x2{s1[2 * e - 4], s1[2 * e - 3]};
+              const f32x2 sh2 = e < 2 ? f32x2{h0[2 * e], h0[2 * e + 1]} : f32x2{h1[2 * e - 4], h1[2 * e - 3]};
+              const f32x2 t = xv * sc2 + sh2;
+              const half2_t r = __builtin_elementwise_max(__builtin_convertvector(t, half2_t), half2_t{(half_t)0.f, (half_t)0.f});
+              o[2 * e] = r[0];
+              o[2 * e + 1] = r[1];
+            }
+            char* slot = dst + n * L::PIECE_BYTES;
+            *reinterpret_cast<half8_t*>(ok ? slot : slot + (8 - pcc) * 16) = o;
+          }
+        };
+        piece(std::integral_constant<int, 0>{}, std::integral_constant<int, IPW - 2>{});  // pieces every wave has (4 x 8 - 2 = 30)
+        if (w4 * IPW + IPW - 1 < L::NPIECE) piece(std::integral_constant<int, IPW - 2>{}, std::integral_constant<int, IPW>{});
+      }
+      return;
+    }
     char* dst = gpatch + buf * PATCH_SLOT + w4 * (IPW * 1024);
     int ln = lane;
     asm volatile("" : "+v"(ln));
@@ -267,7 +349,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
         resv[it] = buffer_load16(p.res, p.y_bytes, vo);
       }
     }
-    if constexpr (M16) {
+    if constexpr (M16 && AMP3_FRING > 0) {
+      // 72 pixel-row fragments (18 k32 steps x 4 rows, tap-major), each feeding two MFMAs (the wave's two 16-channel halves), through a
+      // rolling ring of eight fragment registers: fragment f + AMP3_FRING is requested right before the MFMAs of fragment f, so a read
+      // has AMP3_FRING x 32 MFMA cycles to come back (the step-wise form below: 128) -- the ablation showed the MFMA phase waiting on
+      // its fragment reads (146 -> 98 us without them).  LDS returns a wave's reads in order: the compiler's counted lgkmcnt waits
+      // leave the younger reads in flight.  Accumulation order per accumulator unchanged (bit-identical results).
+      constexpr int NF = 72, D = AMP3_FRING;
+      static_assert(D >= 1 && D <= 7, "ring of eight registers");
+      half8_t fr[8];
+      auto frag = [&](int f) {
+        const int s = f >> 2, pb = f & 3, tap = s >> 1, ks2 = s & 1, kh = tap / 3, kw = tap - kh * 3;
+        return *reinterpret_cast<const half8_t*>(pt + ((pb + kh) * PW + kw) * PP + ks2 * 64);
+      };
+      if constexpr (!(AMP3_ABL & 4)) {
+#pragma unroll
+        for (int f = 0; f < D; ++f) fr[f] = frag(f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + D < NF && !(AMP3_ABL & 4)) fr[(f + D) & 7] = frag(f + D);
+        __builtin_amdgcn_sched_barrier(0);
+        const int s = f >> 2, pb = f & 3;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!(AMP3_ABL & 2)) {
+#pragma unroll
+          for (int ca = 0; ca < 2; ++ca)
+            acc4[pb][ca] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s * 2 + ca], fr[f & 7], s == 0 ? z : acc4[pb][ca], 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(fr[f & 7]));
+          if (s == 0) { acc4[pb][0] = z; acc4[pb][1] = z; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (M16) {
       // 18 k32 steps (tap-major, two per tap): the four pixel-row fragments of step s+1 are requested before the eight MFMAs of step s
 #pragma unroll
       for (int s = 0; s < 18 + 1; ++s) {
