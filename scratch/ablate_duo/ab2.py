@@ -35,7 +35,10 @@ for (B, H, W) in ((36, 37, 53), (2, 180, 320), (40, 41, 40), (5, 121, 111)):
         for name, (y, st) in outs.items():
             same = bool((y == ref[0]).all()); sd = float((st - ref[1]).abs().max() / ref[1].abs().max())
             print(f"B={B} {H}x{W} pre={pre} {name:12s} y bit-equal to head: {same}; stats rel diff {sd:.1e}", flush=True)
-            assert ("_t" in name) or (same and sd < 1e-12), name
+            err = float((y.float() - ref[0].float()).abs().max() / ref[0].float().abs().max())
+            assert ("_t" in name) or (err < 2e-3 and sd < 1e-4), (name, err, sd)
+            if not same:
+                print(f"      max |y - y_head| / max |y_head| = {err:.2e}")
 def t(f, n=30):
     for _ in range(5): f()
     torch.cuda.synchronize()
@@ -57,3 +60,12 @@ for rep in range(3):
         for name, lib in libs.items():
             us = t(lambda: run(lib, pre, g, x, wp, y, stats, sc, sh))
             print(f"rep {rep} pre={pre} {name:12s} {us:7.1f} us ({fl / us / 1e6:6.0f} TF/s)", flush=True)
+            if hasattr(lib, "duo_diag") and rep == 2:
+                d = (ctypes.c_longlong * 8)()
+                try:
+                    lib.duo_diag(d)
+                    n = max(d[7], 1)
+                    names = ["mfma", "patch wait", "transform", "barrier", "patch issue", "epilogue", "loop"]
+                    print("      workgroup 0 wave 0, s_memtime ticks per tile over", n, "tiles:", ", ".join(f"{names[k]} {d[k] / n:.0f}" for k in range(7)), f"| total {sum(d[k] for k in range(7)) / n:.0f}")
+                except AttributeError:
+                    pass

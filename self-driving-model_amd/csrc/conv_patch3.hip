@@ -25,6 +25,9 @@
 #ifndef AMP3_ABL
 #define AMP3_ABL 0
 #endif
+#ifndef AMP3_ROWREUSE
+#define AMP3_ROWREUSE 1  // M16 form: every patch-row fragment read once per (kw, k-half) and reused by the (output row, vertical tap) pairs on it
+#endif
 #ifndef AMP3_FRING
 #define AMP3_FRING 7  // M16 form: prefetch distance of the fragment ring in fragments (0: the step-wise form, four fragments per eight MFMAs)
 #endif
@@ -33,6 +36,19 @@
 #endif
 
 namespace amp3 {
+
+// Diagnostic build only (scratch/ablate_duo, -DAMP3_DIAG): wave 0 of workgroup 0 sums the s_memtime cycles of its tile-loop phases
+#ifdef AMP3_DIAG
+__device__ long long g_duo_diag[8];
+#define AMP3_STAMP(k)                                  \
+  do {                                                 \
+    const long long t_now_ = __builtin_readcyclecounter(); \
+    dg[k] += t_now_ - t_last;                          \
+    t_last = t_now_;                                   \
+  } while (0)
+#else
+#define AMP3_STAMP(k) do { } while (0)
+#endif
 
 constexpr int TH = 8, TW = 16;             // output tile of one group
 constexpr int PH = TH + 2, PW = TW + 2;    // input patch
@@ -325,7 +341,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
   if (tile + per_xcd < tend) issue_patch(tile + per_xcd, 1);
 
   int buf = 0;
+#ifdef AMP3_DIAG
+  long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = __builtin_readcyclecounter();
+#endif
   for (; tile < tend; tile += per_xcd) {
+    AMP3_STAMP(6);  // loop overhead / previous iteration's tail
     // ------------------------------- MFMA phase -------------------------------
     // 36 k16 steps (tap-major), software-pipelined by hand: the two pixel-fragment reads of step s+1 are issued before
     // the two MFMAs of step s.  The wait is the builtin so that hipcc's waitcnt pass sees it (by itself it emits
@@ -349,7 +370,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
         resv[it] = buffer_load16(p.res, p.y_bytes, vo);
       }
     }
-    if constexpr (M16 && AMP3_FRING > 0) {
+    if constexpr (M16 && AMP3_ROWREUSE) {
+      // Row-reuse schedule: the wave's four output rows x three vertical taps touch SIX patch rows, and the fragment of patch row R
+      // (for one horizontal tap kw and one 32-channel half ks2) serves every (output row pb, vertical tap kh) with pb + kh = R.  So
+      // per (kw, ks2) the six row fragments are read ONCE (36 reads per tile instead of 72: the LDS port, which the fragment reads
+      // of eight waves saturate exactly when the MFMA pipes are busy, carries half the bytes) and a sliding window of four of them
+      // feeds the eight MFMAs of each kh step.  Eight fragment registers: fragment q = 6 * j + R lives in register q & 7; the four
+      // reads of (j, kh = 0) fetch rows 4-5 and the next j's rows 0-1, kh = 1 / 2 one row each -- every read is issued at least one
+      // step (128 MFMA cycles) before its first use, the compiler's counted lgkmcnt waits leave the younger ones in flight.
+      // Accumulation order per output: (kw, ks2) outer, kh inner.
+      half8_t fr[8];
+      auto frag = [&](int q) {
+        const int j = q / 6, R = q - j * 6, kw = j >> 1, ks2 = j & 1;
+        return *reinterpret_cast<const half8_t*>(pt + (R * PW + kw) * PP + ks2 * 64);
+      };
+      if constexpr (!(AMP3_ABL & 4)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fr[q] = frag(q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        const int j = s / 3, kh = s - j * 3, kw = j >> 1, ks2 = j & 1;
+        if constexpr (!(AMP3_ABL & 4)) {
+          if (kh == 0) {
+#pragma unroll
+            for (int q = 6 * j + 4; q < 6 * j + 8; ++q)
+              if (q < 36) fr[q & 7] = frag(q);
+          } else if (6 * j + 7 + kh < 36) {
+            fr[(6 * j + 7 + kh) & 7] = frag(6 * j + 7 + kh);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!(AMP3_ABL & 2)) {
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int ca = 0; ca < 2; ++ca)
+              acc4[pb][ca] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[((kh * 3 + kw) * 2 + ks2) * 2 + ca], fr[(6 * j + kh + pb) & 7],
+                                                                    s == 0 ? z : acc4[pb][ca], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) {
+            asm volatile("" ::"v"(fr[(6 * j + kh + pb) & 7]));
+            if (s == 0) { acc4[pb][0] = z; acc4[pb][1] = z; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (M16 && AMP3_FRING > 0) {
       // 72 pixel-row fragments (18 k32 steps x 4 rows, tap-major), each feeding two MFMAs (the wave's two 16-channel halves), through a
       // rolling ring of eight fragment registers: fragment f + AMP3_FRING is requested right before the MFMAs of fragment f, so a read
       // has AMP3_FRING x 32 MFMA cycles to come back (the step-wise form below: 128) -- the ablation showed the MFMA phase waiting on
@@ -447,6 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
     // done; after the barrier the next patch is complete and nobody reads the current one any more -- so the patch after
     // next goes into the buffer just read, two tiles ahead of its use (an LDS-DMA from HBM takes longer than one MFMA
     // phase under load).  Raw barrier + asm wait: __syncthreads() would do, the explicit form documents what is ordered.
+    AMP3_STAMP(0);  // MFMA phase (issue)
 #if AMP3_VMCNT4
     // the four stores of the previous tile's epilogue are the wave's youngest vector-memory operations: leave them in flight
     // (the next patch's pieces, issued before them, have landed once only four remain outstanding)
@@ -455,14 +526,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+    AMP3_STAMP(1);  // wait for the next patch's pieces
     if (pre && tile + per_xcd < tend) {
       transform_patch(tile + per_xcd, buf ^ 1);  // this wave's share of the next patch has landed: rewrite it in place
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    AMP3_STAMP(2);  // input transform
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    AMP3_STAMP(3);  // barrier
     if (!(AMP3_ABL & 1) && tile + 2 * per_xcd < tend) issue_patch(tile + 2 * per_xcd, buf);
     buf ^= 1;
+    AMP3_STAMP(4);  // patch issue
 
     // ------------------------------- epilogue -------------------------------
     // acc[tm][r] = out(pixel (row hsel*4 + tm*2 + frow, col fcol), channel tn*32 + 8*(r>>2) + 4*kg + (r&3))
@@ -552,7 +627,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64n64_duo_k(const Patch3Param
       else asm volatile("" ::"v"(v), "v"(vo));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the next tile's writes
+    AMP3_STAMP(5);  // epilogue
+#ifdef AMP3_DIAG
+    dg[7] += 1;
+#endif
   }
+#ifdef AMP3_DIAG
+  if (blockIdx.x == 0 && tid == 0)
+    for (int k = 0; k < 8; ++k) g_duo_diag[k] = dg[k];
+#endif
 
   if (!EPI && p.stats != nullptr) {
     // fold the 32 pixel lanes of each half-wave (xor < 32 stays inside the half), then the 4 waves that share a channel
