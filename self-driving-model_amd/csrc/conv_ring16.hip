@@ -474,8 +474,10 @@ int am_conv_ring16_f16(const am_conv_geom* g, const void* x, const void* w, cons
     if (tile_out) *tile_out = 3;
     return launch<128, 256, 2, 4, 3, false>(p, s);
   }
-  // (the 256x128 tile of this generation lost to conv_ring_k<256,128>: its half K-steps are 8 MFMAs of 16 cycles, too short to
-  // cover the fragment reads issued behind the barrier -- 671 vs 784 TFLOP/s on the layer2 shape -- so it is not dispatched)
+  // (the 256x128 tile of this generation: with the block schedule it lost to conv_ring_k<256,128> -- its half K-steps are 8 MFMAs of 16
+  // cycles, too short to cover the fragment reads issued behind the barrier: 671 vs 784 TFLOP/s on the layer2 shape; with the
+  // interleaved schedule (SCHED 3) it is 3-4 % ahead on the 64 -> 128 stride-2 entry and on layer2, equal on the 256 / 512 -> 128
+  // shapes and the 1x1 shortcuts (scratch, late round 3) -- ~0.02 ms of a 12 ms step: not dispatched)
   return AM_ERR_UNSUPPORTED;
 }
 
