@@ -561,10 +561,12 @@ __global__ __launch_bounds__(256) void lsap_reg_k(const float* __restrict__ cost
 // does: the first tied column in scan order of its `remaining` array wins, so each slot tracks its column's position there
 // (remaining[it] = nc - 1 - it at the start of an augmentation; removing a position moves the LAST element into it); an
 // unassigned column wins a tie against assigned ones wherever it stands.  Ties among UNASSIGNED columns depend on positions this
-// solver does not track: whenever one could matter -- the two cheapest unassigned entries of a row at the same reduced cost
-// (equal or rounding-merged costs), two rows proposing different columns at the same value, a row's list exhausted -- the
-// image is handed back (flags[b] = 2) and the general kernel, which reproduces the full tie rule, solves it in the same
-// stream.  Infeasible problems (status -1) go the same way.  tests/test_lsap_split_model_cpu.py holds a line-by-line Python model
+// solver does not track: whenever one DECIDES a selection -- the value the search finally selects is shared by two unassigned
+// columns: the two cheapest unassigned entries of a row at the same reduced cost (equal or rounding-merged costs), or two rows
+// proposing different columns at that value -- or a row's list is exhausted, the image is handed back (flags[b] = 2) and the
+// general kernel, which reproduces the full tie rule, solves it in the same stream.  (Until late in round 3 every such tie
+// handed back when it was SEEN, selected or not: two equal fp32 costs among a row's cheapest are common at 920 queries and
+// costs of ~3,000 -- one image in ten of the cfg3 step; a tie above the selected value changes no selection of scipy's.)  Infeasible problems (status -1) go the same way.  tests/test_lsap_split_model_cpu.py holds a line-by-line Python model
 // of this algorithm to scipy on thousands of problems (0 hand-backs in 1,500 random ones, every answer scipy's).
 struct TopEnt {
   float c;
@@ -700,7 +702,8 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
     int pos = lane < nasg ? nc - 1 - acol : -1;
     int n_rem = nc;
     unsigned SRm = 0;
-    double ub_v = INFINITY, min_val = 0.0;
+    double ub_v = INFINITY, min_val = 0.0, tie_v = 0.0;
+    bool have_tie = false;
     int ub_col = -1, ub_row = -1, sink = -1;
     int i = cur;
     for (int guard = 0; guard <= 64; ++guard) {
@@ -732,9 +735,12 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
       }
       // a second unassigned entry must be KNOWN not to tie with the first: list exhausted before the matrix is -> hand back
       if (!have2 && ktop < nc) { fallback = true; break; }
-      if (have2 && r2 == r1 && r1 < INFINITY) { fallback = true; break; }
+      // A tie among UNASSIGNED columns matters only if its value is the one the search finally selects (scipy then takes the last
+      // tied column in the scan order of its `remaining` array, which this representation does not track): remember the value and
+      // hand back at selection time.  The running minimum only decreases, so an older tie at a larger value is dead.
       if (r1 < ub_v) { ub_v = r1; ub_col = j1; ub_row = i; }
-      else if (r1 == ub_v && r1 < INFINITY && j1 != ub_col) { fallback = true; break; }
+      else if (r1 == ub_v && r1 < INFINITY && j1 != ub_col) { tie_v = ub_v; have_tie = true; }
+      if (have2 && r2 == r1 && r1 < INFINITY && r1 <= ub_v) { tie_v = r1; have_tie = true; }
       // the assigned columns that are not scanned yet
       double cand = INFINITY;
       if (lane < nasg && !insc) {
@@ -746,6 +752,7 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
       const double m = wave_min_f64(cand);
       if (ub_v <= m) {  // an unassigned column is the closest (scipy: it also wins a tie with assigned ones, wherever it stands)
         if (ub_v == INFINITY) { fallback = true; break; }  // infeasible: the general kernel reports it
+        if (have_tie && tie_v == ub_v) { fallback = true; break; }  // the selected minimum is shared by two unassigned columns
         min_val = ub_v; sink = ub_col;
         break;
       }
