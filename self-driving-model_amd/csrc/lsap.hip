@@ -687,6 +687,20 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
     }
   __syncthreads();
   const int ktop = nc < ktop_cap ? nc : ktop_cap;
+  // Row lane i caches its row's first two UNASSIGNED list entries (costs c1 <= c2, columns j1 / j2, list index k2 of the second):
+  // nothing is assigned yet, so they are entries 0 and 1.  A column becomes assigned only at the end of an augmentation (the
+  // sink), so the cache is repaired there -- once per augmentation, all rows at once -- and a search step reads it with four
+  // v_readlane instead of a list gather, a bpermute of the assigned-column bitmap, a ballot and two more lane reads.
+  float rc1 = INFINITY, rc2 = INFINITY;
+  int rj1 = -1, rj2 = -1, rk2 = 1;
+  if (lane < nr) {
+    const TopEnt e0 = tl[lane * ktop_cap];
+    if (e0.j >= 0) { rc1 = e0.c; rj1 = e0.j; }
+    if (ktop > 1) {
+      const TopEnt e1 = tl[lane * ktop_cap + 1];
+      if (e1.j >= 0) { rc2 = e1.c; rj2 = e1.j; }
+    }
+  }
 
   // lane l < nr doubles as ROW l (dual u, the slot its column sits in) and as SLOT l (the l-th column that became assigned: its
   // index, dual v, assigned row and, per augmentation, shortest-path cost / path predecessor / scanned flag)
@@ -710,27 +724,16 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
       if (guard == 64) { fallback = true; break; }  // (cannot happen: every step scans a new slot or ends the search)
       SRm |= 1u << i;
       const double ui = readlane_f64(u, i);
-      // row i's first two UNASSIGNED list entries (lane k looks at entry k)
-      TopEnt e = TopEnt{INFINITY, -1};
-      if (lane < ktop) e = tl[i * ktop_cap + lane];
-      const int ej = e.j;
-      const unsigned om = (unsigned)__builtin_amdgcn_ds_bpermute((ej & 63) * 4, (int)amask);
-      const bool un = lane < ktop && ej >= 0 && !((om >> ((ej >> 6) & 15)) & 1u);
-      const unsigned long long um = __ballot(un);
+      // row i's first two unassigned list entries, from its lane's cache
       double r1 = INFINITY, r2 = INFINITY;
-      int j1 = -1;
-      bool have2 = false;
-      if (um != 0) {
-        const int k1 = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)um) - 1);
-        const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.c), k1));
-        j1 = __builtin_amdgcn_readlane(ej, k1);
+      const int j1 = __builtin_amdgcn_readlane(rj1, i);
+      const bool have2 = __builtin_amdgcn_readlane(rj2, i) >= 0;
+      if (j1 >= 0) {
+        const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rc1), i));
         r1 = (min_val + (double)c1) - ui;  // scipy: minVal + cost - u[i] - v[j], v[j] = 0 for a never-scanned column
-        const unsigned long long um2 = um & (um - 1);
-        if (um2 != 0) {
-          const int k2 = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)um2) - 1);
-          const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.c), k2));
+        if (have2) {
+          const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rc2), i));
           r2 = (min_val + (double)c2) - ui;
-          have2 = true;
         }
       }
       // a second unassigned entry must be KNOWN not to tie with the first: list exhausted before the matrix is -> hand back
@@ -797,6 +800,30 @@ __global__ __launch_bounds__(64) void lsap_split_k(const float* __restrict__ cos
       if (lane == r) sor = js;
       js = t;
       if (r == cur) break;
+    }
+    // repair the rows' caches: column `sink` is assigned now.  A row that had it first promotes its second entry; either way the
+    // row then needs a new second entry: the next list entry whose column is not assigned (bit lookup in the lane that owns it).
+    {
+      bool need = false;
+      if (lane < nr) {
+        if (rj1 == sink) { rc1 = rc2; rj1 = rj2; need = true; }
+        else if (rj2 == sink) need = true;
+        if (need) { rc2 = INFINITY; rj2 = -1; }
+      }
+      bool scanning = need && rj1 >= 0;  // (a row without a first entry has nothing finite left)
+      for (int guard = 0; guard <= 64 && __ballot(scanning) != 0; ++guard) {
+        TopEnt e = TopEnt{INFINITY, -1};
+        const bool in_list = scanning && rk2 + 1 < ktop;
+        if (in_list) e = tl[lane * ktop_cap + rk2 + 1];
+        const unsigned om = (unsigned)__builtin_amdgcn_ds_bpermute((e.j & 63) * 4, (int)amask);  // (every lane takes part)
+        if (scanning) {
+          if (!in_list || e.j < 0) scanning = false;  // list exhausted / nothing finite left: no second entry
+          else {
+            rk2 += 1;
+            if (!((om >> ((e.j >> 6) & 15)) & 1u)) { rc2 = e.c; rj2 = e.j; scanning = false; }
+          }
+        }
+      }
     }
   }
   if (fallback) {
